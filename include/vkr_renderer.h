@@ -1,0 +1,222 @@
+/*
+ * vkr_renderer.h — C ABI of the MI355X-native Sun Temple renderer.
+ *
+ * One call, vkr_render(), replaces the body of the reference's
+ * record_commands() + submit_commands() + present
+ * (main/main.cpp:3709-4342, called from the frame loop at main/main.cpp:1367-1400):
+ * it takes the same per-frame information (the five uniform blocks, the
+ * extent, the three UserState mode fields) and produces the image the
+ * reference would present, as tightly packed sRGB-encoded RGBA8, plus the
+ * integer side buffers used for parity checks.
+ *
+ * Conventions
+ *  - Every function returns 0 on success and a non-zero VKR_E_* code on
+ *    failure; vkr_last_error() then returns a thread-local message.  No C++
+ *    exception crosses this boundary (the reference throws labutils::Error,
+ *    utils/error.hpp:16-26, and catches it once in main, main/main.cpp:1413-1418).
+ *  - Matrices are column-major float[16], exactly glm::mat4 in memory.
+ *  - A context belongs to one GPU and is not thread-safe; different contexts
+ *    are independent.
+ *  - Pointers in vkr_frame_out may be host or device memory (unified
+ *    addressing tells them apart); NULL means "not wanted".
+ */
+#ifndef VKR_RENDERER_H
+#define VKR_RENDERER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VKR_OK 0
+#define VKR_E_INVALID 1   /* bad argument */
+#define VKR_E_DEVICE 2    /* HIP runtime error */
+#define VKR_E_IO 3        /* file could not be read / parsed */
+#define VKR_E_NOMEM 4     /* host or device allocation failed */
+#define VKR_E_LIMIT 5     /* a stated size limit was exceeded */
+
+#define VKR_NO_TEXTURE 0xffffffffu /* main/baked_model.hpp:92-94 */
+#define VKR_NUM_LIGHTS 21          /* main/main.cpp:222, deferredShading.frag:5 */
+#define VKR_NO_TRIANGLE 0xffffffffu
+
+typedef struct vkr_context vkr_context; /* one per GPU */
+typedef struct vkr_scene vkr_scene;     /* device-resident copy of a BakedModel */
+
+/* ---- scene hand-off: mirrors BakedModel (main/baked_model.hpp:80-115) ---- */
+
+/* One decoded texture: what stbi_load(path,...,4) returns after the vertical
+ * flip the reference asks for (utils/vkimage.cpp:62-65), i.e. level 0 as it
+ * is copied into the VkImage.  space: 0 = unorm, 1 = srgb
+ * (ETextureSpace, main/baked_model.hpp:74-78). */
+typedef struct vkr_texture_desc {
+	const uint8_t* rgba8; /* width*height*4 bytes, row 0 first */
+	uint32_t width, height;
+	uint8_t space;
+	uint8_t channels; /* BakedTextureInfo::channels, informational */
+	uint8_t _pad[6];
+} vkr_texture_desc;
+
+/* BakedMaterialInfo (main/baked_model.hpp:87-95), same field order. */
+typedef struct vkr_material_desc {
+	uint32_t baseColorTextureId;
+	uint32_t roughnessTextureId;
+	uint32_t metalnessTextureId;
+	uint32_t alphaMaskTextureId; /* VKR_NO_TEXTURE if none */
+	uint32_t normalMapTextureId;
+	uint32_t emissiveTextureId; /* never sampled, as in the reference */
+} vkr_material_desc;
+
+/* BakedMeshData (main/baked_model.hpp:97-108).  normals and tangents may be
+ * NULL: no fragment shader of the reference reads them. */
+typedef struct vkr_mesh_desc {
+	uint32_t materialId;
+	uint32_t vertexCount;
+	uint32_t indexCount;
+	uint32_t _pad;
+	const float* positions;        /* vertexCount * 3 */
+	const float* texcoords;        /* vertexCount * 2 */
+	const float* normals;          /* vertexCount * 3 or NULL */
+	const float* tangents;         /* vertexCount * 4 or NULL */
+	const uint32_t* tangentsComp;  /* vertexCount, A2R10G10B10 packed TBN quaternion */
+	const uint32_t* indices;       /* indexCount, triangle list */
+} vkr_mesh_desc;
+
+typedef struct vkr_scene_desc {
+	uint32_t textureCount, materialCount, meshCount, _pad;
+	const vkr_texture_desc* textures;
+	const vkr_material_desc* materials;
+	const vkr_mesh_desc* meshes;
+} vkr_scene_desc;
+
+/* ---- per-frame inputs: mirrors struct Uniforms (main/main.cpp:203-240) ---- */
+
+typedef struct vkr_scene_uniform { /* glsl::SceneUniform, main/main.cpp:205-210 */
+	float camera[16];
+	float projection[16];
+	float projCam[16];
+	float camPos[4];
+} vkr_scene_uniform;
+
+typedef struct vkr_light_uniform { /* glsl::LightUniform, main/main.cpp:212-215 */
+	float lightPos[4];
+	float lightColour[4];
+} vkr_light_uniform;
+
+typedef struct vkr_debug_uniform { /* glsl::DebugUniform, main/main.cpp:217-219 */
+	int32_t debug;
+} vkr_debug_uniform;
+
+typedef struct vkr_multiple_lights { /* glsl::MultipleLights, main/main.cpp:221-223 */
+	vkr_light_uniform light[VKR_NUM_LIGHTS];
+} vkr_multiple_lights;
+
+typedef struct vkr_depth_mvp { /* glsl::DepthMVP, main/main.cpp:225-227 */
+	float depthMVP[16];
+} vkr_depth_mvp;
+
+typedef struct vkr_uniforms { /* struct Uniforms, main/main.cpp:234-240 */
+	vkr_scene_uniform sceneUniforms;
+	vkr_light_uniform lightUniforms;
+	vkr_debug_uniform debugUniforms;
+	vkr_multiple_lights multipleLightsUniform;
+	vkr_depth_mvp depthMVPUniform;
+} vkr_uniforms;
+
+/* flags for vkr_frame_params::flags */
+#define VKR_FRAME_DEFAULT 0u
+
+typedef struct vkr_frame_params {
+	uint32_t width, height; /* VkExtent2D aExtent, main/main.cpp:3714 */
+	uint32_t shadow_size;   /* 0 = 2048 (main/main.cpp:3958) */
+	/* UserState mode fields (main/main.cpp:117-119); precedence as in
+	 * record_commands: deferred && !mosaic, then !mosaic && debug==1, then
+	 * debug 5/6, then other debug values, then mosaic (main/main.cpp:3836-4195). */
+	int32_t debugVisualisation;
+	int32_t mosaicEffect;
+	int32_t deferredShading;
+	/* sort-first sub-rectangle [x0,x1) x [y0,y1) in pixels, even-aligned;
+	 * all four zero = the whole frame.  Output buffers are rectangle-sized. */
+	uint32_t rect_x0, rect_y0, rect_x1, rect_y1;
+	uint32_t flags;
+	uint32_t _pad;
+	vkr_uniforms uniforms;
+} vkr_frame_params;
+
+/* Output buffers, each (rect width * rect height) elements, row 0 = top,
+ * tightly packed, except shadow_map which is shadow_size^2. */
+typedef struct vkr_frame_out {
+	void* rgba8;           /* the presented image: R8G8B8A8, RGB sRGB-encoded (utils/vulkan_window.cpp:349-360) */
+	uint32_t* tri_id;      /* submission-order primitive index of the visible fragment, VKR_NO_TRIANGLE if none */
+	uint32_t* depth_bits;  /* IEEE-754 bits of the D32 depth attachment */
+	uint8_t* mip_level;    /* floor(textureQueryLod().x) of the base-colour texture (debug view 2), 0xff if no fragment */
+	uint8_t* stencil;      /* S8 counter of the overdraw (5) / overshading (6) views */
+	uint16_t* gbuf_normal; /* RGBA16F attachment 1 of the deferred pass (normal.xyz, metalness) */
+	uint16_t* gbuf_albedo; /* RGBA16F attachment 2 of the deferred pass (albedo.rgb, roughness) */
+	float* shadow_map;     /* D32 shadow map of the forward path */
+} vkr_frame_out;
+
+/* ---- functions ---- */
+
+const char* vkr_last_error(void);
+
+/* Creates a context on HIP device `device` with its own stream. */
+int vkr_context_create(int device, vkr_context** out);
+void vkr_context_destroy(vkr_context* ctx);
+
+/* Replaces load_baked_model() + the texture / mesh upload loops
+ * (main/baked_model.hpp:117, main/main.cpp:752-760, 870-1095): copies the
+ * arrays to the GPU, builds the mip chains (utils/vkimage.cpp:163-216). */
+int vkr_scene_create(vkr_context* ctx, const vkr_scene_desc* desc, vkr_scene** out);
+/* Same, reading a ".comp5892mesh" file (variant "21-tan",
+ * main/baked_model.cpp:70-174) and the PNG textures it names. */
+int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** out);
+void vkr_scene_destroy(vkr_scene* scene);
+/* number of triangles / vertices held by the scene */
+int vkr_scene_stats(const vkr_scene* scene, uint64_t* triangles, uint64_t* vertices, uint64_t* texture_bytes);
+/* Reads mip level `level` of texture `tex` back (RGBA8); for parity tests of
+ * the mip chain against vkCmdBlitImage semantics (utils/vkimage.cpp:165-216). */
+int vkr_scene_read_texture_level(const vkr_scene* scene, uint32_t tex, uint32_t level,
+                                 uint8_t* rgba8_out, uint32_t* width, uint32_t* height);
+
+/* Replaces record_commands + submit_commands for one frame
+ * (main/main.cpp:1367-1389).  Asynchronous on the context's stream; params
+ * are snapshotted on entry like vkCmdUpdateBuffer does (main/main.cpp:3741).
+ * Output pointers must stay valid until vkr_wait(). */
+int vkr_render(vkr_context* ctx, const vkr_scene* scene, const vkr_frame_params* params,
+               const vkr_frame_out* out);
+/* The fence: blocks until every frame submitted on the context is complete
+ * (vkWaitForFences, main/main.cpp:1268). */
+int vkr_wait(vkr_context* ctx);
+
+/* Host-side uniform helpers, same arithmetic as the reference's
+ * update_scene_uniforms (main/main.cpp:3681-3693),
+ * update_depth_mvp_uniforms (main/main.cpp:3699-3707) and the constant light
+ * tables of the frame loop (main/main.cpp:1313-1352). */
+void vkr_update_scene_uniforms(vkr_scene_uniform* out, uint32_t width, uint32_t height,
+                               const float camera2world[16]);
+void vkr_update_depth_mvp_uniforms(vkr_depth_mvp* out, const float lightPos[4]);
+void vkr_default_lights(vkr_light_uniform* forwardLight, vkr_multiple_lights* braziers);
+/* Fills every block of `u` for a camera pose and debug mode, as the frame
+ * loop does at main/main.cpp:1307-1359. */
+void vkr_make_uniforms(vkr_uniforms* u, uint32_t width, uint32_t height,
+                       const float camera2world[16], int32_t debugVisualisation);
+
+/* ---- measurement ---- */
+
+/* Stage timing with HIP events on the context's stream.  Stage names are
+ * returned by vkr_stage_name(); times are accumulated per stage since the
+ * last vkr_profile_reset(). */
+int vkr_profile_enable(vkr_context* ctx, int on);
+int vkr_profile_reset(vkr_context* ctx);
+int vkr_stage_count(void);
+const char* vkr_stage_name(int stage);
+/* Synchronises, then returns accumulated milliseconds and launch count. */
+int vkr_profile_get(vkr_context* ctx, int stage, double* total_ms, uint64_t* launches);
+/* The HIP stream (hipStream_t) the context launches on. */
+void* vkr_context_stream(vkr_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKR_RENDERER_H */

@@ -1,0 +1,179 @@
+// ref_fixtures.cpp — TEST INFRASTRUCTURE.  Generates golden vectors by calling
+// the parts of the reference that compile without Vulkan: glm (vendored under
+// third_party/glm), labutils' angle helpers (utils/angle.hpp), the bake tool's
+// make_indexed_mesh (main-bake/index_mesh.cpp + third_party/tgen) and the
+// baked-model loader (main/baked_model.cpp).  It is compiled against the
+// sources where they lie under /root/reference (see oracle/Makefile, target
+// _ref) and its outputs are committed under tests/golden/.  Nothing here is
+// copied from the reference; the reference cannot travel to the GPU box.
+//
+// usage: ref_fixtures matrices            -> JSON on stdout
+//        ref_fixtures tangents            -> JSON on stdout
+//        ref_fixtures loadmodel <file>    -> JSON on stdout
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <glm/glm.hpp>
+#include <glm/gtc/matrix_transform.hpp>
+#include <glm/gtx/transform.hpp>
+
+#include "../utils/angle.hpp"
+#include "../main-bake/index_mesh.hpp"
+#include "../main/baked_model.hpp"
+
+namespace lut = labutils;
+using namespace labutils::literals;
+
+static void print_mat(const char* name, glm::mat4 const& m, bool last = false)
+{
+	std::printf("    \"%s\": [", name);
+	for (int c = 0; c < 4; c++)
+		for (int r = 0; r < 4; r++) {
+			std::uint32_t bits;
+			float v = m[c][r];
+			std::memcpy(&bits, &v, 4);
+			std::printf("%u%s", bits, (c == 3 && r == 3) ? "" : ", ");
+		}
+	std::printf("]%s\n", last ? "" : ",");
+}
+
+static int do_matrices()
+{
+	// The same glm calls, with the same arguments, as update_scene_uniforms
+	// (main/main.cpp:3681-3693) and update_depth_mvp_uniforms (main/main.cpp:3699-3707).
+	constexpr auto kCameraFov = 60.0_degf;
+	struct Pose { const char* name; glm::mat4 c2w; };
+	std::vector<Pose> poses;
+	poses.push_back({ "identity", glm::identity<glm::mat4>() });
+	poses.push_back({ "p1", glm::translate(glm::vec3(0.f, -1.f, -30.f)) });
+	poses.push_back({ "p2", glm::translate(glm::vec3(0.f, -2.f, -70.f)) * glm::rotate(3.14159265358979f, glm::vec3(0.f, 1.f, 0.f)) });
+	poses.push_back({ "p3", glm::translate(glm::vec3(1.5f, 0.25f, -12.f)) * glm::rotate(0.35f, glm::vec3(0.f, 1.f, 0.f)) * glm::rotate(-0.2f, glm::vec3(1.f, 0.f, 0.f)) });
+	const unsigned sizes[][2] = { { 1280, 720 }, { 1920, 1080 }, { 3840, 2160 }, { 64, 36 } };
+	std::printf("{\n  \"scene\": [\n");
+	bool first = true;
+	for (auto const& sz : sizes)
+		for (auto const& p : poses) {
+			const float aspect = sz[0] / float(sz[1]);
+			glm::mat4 projection = glm::perspectiveRH_ZO(lut::Radians(kCameraFov).value(), aspect, 0.1f, 100.f);
+			projection[1][1] *= -1.0f;
+			glm::mat4 camera = glm::inverse(p.c2w);
+			glm::mat4 projCam = projection * camera;
+			std::printf("%s  {\n    \"pose\": \"%s\", \"width\": %u, \"height\": %u,\n", first ? "" : ",\n", p.name, sz[0], sz[1]);
+			print_mat("camera2world", p.c2w);
+			print_mat("camera", camera);
+			print_mat("projection", projection);
+			print_mat("projCam", projCam);
+			print_mat("invCamera", glm::inverse(camera));
+			print_mat("invProjection", glm::inverse(projection), true);
+			std::printf("  }");
+			first = false;
+		}
+	std::printf("\n  ],\n");
+	{
+		glm::vec4 lightPos(-0.2972f, 7.3100f, -11.9532f, 0.0f);
+		glm::mat4 depthProjection = glm::perspectiveRH_ZO(lut::Radians(90.0f).value(), 1.0f, 0.1f, 100.f);
+		depthProjection[1][1] *= -1.0f;
+		glm::mat4 depthView = glm::lookAt(glm::vec3(lightPos), glm::vec3(0.0f, 0.0f, -48.0f), glm::vec3(0.0f, 1.0f, 0.0f));
+		std::printf("  \"depth\": {\n");
+		print_mat("depthProjection", depthProjection);
+		print_mat("depthView", depthView);
+		print_mat("depthMVP", depthProjection * depthView, true);
+		std::printf("  }\n}\n");
+	}
+	return 0;
+}
+
+static int do_tangents()
+{
+	// A small deterministic triangle soup through make_indexed_mesh
+	// (main-bake/index_mesh.cpp:76-228): a bumpy 6x5 grid with varied normals
+	// and a UV mapping that is rotated and mirrored on one half.
+	TriangleSoup soup;
+	auto P = [](int i, int j) {
+		float x = 0.37f * i, z = 0.29f * j;
+		float y = 0.15f * float((i * 7 + j * 3) % 5) + 0.05f * i * j;
+		return glm::vec3(x, y, z);
+	};
+	auto N = [](int i, int j) {
+		glm::vec3 n(0.3f * float((i * 5 + j) % 3 - 1), 1.0f, 0.25f * float((j * 2 + i) % 4 - 2));
+		return glm::normalize(n);
+	};
+	auto T = [](int i, int j) {
+		float u = 0.21f * i + 0.05f * j, v = 0.17f * j - 0.03f * i;
+		if (i >= 3) u = 2.0f - u; // mirrored half
+		return glm::vec2(u, v);
+	};
+	for (int j = 0; j < 4; j++)
+		for (int i = 0; i < 5; i++) {
+			int q[6][2] = { { i, j }, { i + 1, j }, { i + 1, j + 1 }, { i, j }, { i + 1, j + 1 }, { i, j + 1 } };
+			for (auto& c : q) {
+				soup.vert.push_back(P(c[0], c[1]));
+				soup.norm.push_back(N(c[0], c[1]));
+				soup.text.push_back(T(c[0], c[1]));
+			}
+		}
+	IndexedMesh m = make_indexed_mesh(soup);
+	std::printf("{\n  \"vertexCount\": %zu, \"indexCount\": %zu,\n  \"vertices\": [\n", m.vert.size(), m.indices.size());
+	for (std::size_t i = 0; i < m.vert.size(); i++) {
+		auto bits = [](float f) { std::uint32_t b; std::memcpy(&b, &f, 4); return b; };
+		std::printf("    {\"normal\": [%u, %u, %u], \"tangent\": [%u, %u, %u, %u], \"packed\": %u}%s\n",
+			bits(m.norm[i].x), bits(m.norm[i].y), bits(m.norm[i].z),
+			bits(m.tangent[i].x), bits(m.tangent[i].y), bits(m.tangent[i].z), bits(m.tangent[i].w),
+			m.tangentComp[i], i + 1 == m.vert.size() ? "" : ",");
+	}
+	std::printf("  ]\n}\n");
+	return 0;
+}
+
+static std::uint64_t fnv1a(const void* p, std::size_t n, std::uint64_t h = 1469598103934665603ull)
+{
+	auto b = static_cast<const unsigned char*>(p);
+	for (std::size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+	return h;
+}
+
+static int do_loadmodel(const char* path)
+{
+	BakedModel m = load_baked_model(path);
+	std::printf("{\n  \"textures\": [\n");
+	for (std::size_t i = 0; i < m.textures.size(); i++)
+		std::printf("    {\"path\": \"%s\", \"space\": %u, \"channels\": %u}%s\n", m.textures[i].path.c_str(),
+			unsigned(m.textures[i].space), unsigned(m.textures[i].channels), i + 1 == m.textures.size() ? "" : ",");
+	std::printf("  ],\n  \"materials\": [\n");
+	for (std::size_t i = 0; i < m.materials.size(); i++) {
+		auto const& k = m.materials[i];
+		std::printf("    [%u, %u, %u, %u, %u, %u]%s\n", k.baseColorTextureId, k.roughnessTextureId, k.metalnessTextureId,
+			k.alphaMaskTextureId, k.normalMapTextureId, k.emissiveTextureId, i + 1 == m.materials.size() ? "" : ",");
+	}
+	std::printf("  ],\n  \"meshes\": [\n");
+	for (std::size_t i = 0; i < m.meshes.size(); i++) {
+		auto const& d = m.meshes[i];
+		std::printf("    {\"materialId\": %u, \"V\": %zu, \"I\": %zu, \"positions\": \"%016llx\", \"normals\": \"%016llx\", "
+		            "\"texcoords\": \"%016llx\", \"tangents\": \"%016llx\", \"tangentsComp\": \"%016llx\", \"indices\": \"%016llx\"}%s\n",
+			d.materialId, d.positions.size(), d.indices.size(),
+			(unsigned long long)fnv1a(d.positions.data(), d.positions.size() * sizeof(glm::vec3)),
+			(unsigned long long)fnv1a(d.normals.data(), d.normals.size() * sizeof(glm::vec3)),
+			(unsigned long long)fnv1a(d.texcoords.data(), d.texcoords.size() * sizeof(glm::vec2)),
+			(unsigned long long)fnv1a(d.tangents.data(), d.tangents.size() * sizeof(glm::vec4)),
+			(unsigned long long)fnv1a(d.tangentsComp.data(), d.tangentsComp.size() * sizeof(std::uint32_t)),
+			(unsigned long long)fnv1a(d.indices.data(), d.indices.size() * sizeof(std::uint32_t)),
+			i + 1 == m.meshes.size() ? "" : ",");
+	}
+	std::printf("  ]\n}\n");
+	return 0;
+}
+
+int main(int argc, char** argv)
+try {
+	if (argc >= 2 && 0 == std::strcmp(argv[1], "matrices")) return do_matrices();
+	if (argc >= 2 && 0 == std::strcmp(argv[1], "tangents")) return do_tangents();
+	if (argc >= 3 && 0 == std::strcmp(argv[1], "loadmodel")) return do_loadmodel(argv[2]);
+	std::fprintf(stderr, "usage: ref_fixtures matrices|tangents|loadmodel <file>\n");
+	return 2;
+} catch (std::exception const& e) {
+	std::fprintf(stderr, "error: %s\n", e.what());
+	return 1;
+}
