@@ -29,6 +29,12 @@
 extern "C" {
 #endif
 
+#if defined(__GNUC__)
+#define VKR_API __attribute__((visibility("default")))
+#else
+#define VKR_API
+#endif
+
 #define VKR_OK 0
 #define VKR_E_INVALID 1   /* bad argument */
 #define VKR_E_DEVICE 2    /* HIP runtime error */
@@ -158,48 +164,48 @@ typedef struct vkr_frame_out {
 
 /* ---- functions ---- */
 
-const char* vkr_last_error(void);
+VKR_API const char* vkr_last_error(void);
 
 /* Creates a context on HIP device `device` with its own stream. */
-int vkr_context_create(int device, vkr_context** out);
-void vkr_context_destroy(vkr_context* ctx);
+VKR_API int vkr_context_create(int device, vkr_context** out);
+VKR_API void vkr_context_destroy(vkr_context* ctx);
 
 /* Replaces load_baked_model() + the texture / mesh upload loops
  * (main/baked_model.hpp:117, main/main.cpp:752-760, 870-1095): copies the
  * arrays to the GPU, builds the mip chains (utils/vkimage.cpp:163-216). */
-int vkr_scene_create(vkr_context* ctx, const vkr_scene_desc* desc, vkr_scene** out);
+VKR_API int vkr_scene_create(vkr_context* ctx, const vkr_scene_desc* desc, vkr_scene** out);
 /* Same, reading a ".comp5892mesh" file (variant "21-tan",
  * main/baked_model.cpp:70-174) and the PNG textures it names. */
-int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** out);
-void vkr_scene_destroy(vkr_scene* scene);
+VKR_API int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** out);
+VKR_API void vkr_scene_destroy(vkr_scene* scene);
 /* number of triangles / vertices held by the scene */
-int vkr_scene_stats(const vkr_scene* scene, uint64_t* triangles, uint64_t* vertices, uint64_t* texture_bytes);
+VKR_API int vkr_scene_stats(const vkr_scene* scene, uint64_t* triangles, uint64_t* vertices, uint64_t* texture_bytes);
 /* Reads mip level `level` of texture `tex` back (RGBA8); for parity tests of
  * the mip chain against vkCmdBlitImage semantics (utils/vkimage.cpp:165-216). */
-int vkr_scene_read_texture_level(const vkr_scene* scene, uint32_t tex, uint32_t level,
+VKR_API int vkr_scene_read_texture_level(const vkr_scene* scene, uint32_t tex, uint32_t level,
                                  uint8_t* rgba8_out, uint32_t* width, uint32_t* height);
 
 /* Replaces record_commands + submit_commands for one frame
  * (main/main.cpp:1367-1389).  Asynchronous on the context's stream; params
  * are snapshotted on entry like vkCmdUpdateBuffer does (main/main.cpp:3741).
  * Output pointers must stay valid until vkr_wait(). */
-int vkr_render(vkr_context* ctx, const vkr_scene* scene, const vkr_frame_params* params,
+VKR_API int vkr_render(vkr_context* ctx, const vkr_scene* scene, const vkr_frame_params* params,
                const vkr_frame_out* out);
 /* The fence: blocks until every frame submitted on the context is complete
  * (vkWaitForFences, main/main.cpp:1268). */
-int vkr_wait(vkr_context* ctx);
+VKR_API int vkr_wait(vkr_context* ctx);
 
 /* Host-side uniform helpers, same arithmetic as the reference's
  * update_scene_uniforms (main/main.cpp:3681-3693),
  * update_depth_mvp_uniforms (main/main.cpp:3699-3707) and the constant light
  * tables of the frame loop (main/main.cpp:1313-1352). */
-void vkr_update_scene_uniforms(vkr_scene_uniform* out, uint32_t width, uint32_t height,
+VKR_API void vkr_update_scene_uniforms(vkr_scene_uniform* out, uint32_t width, uint32_t height,
                                const float camera2world[16]);
-void vkr_update_depth_mvp_uniforms(vkr_depth_mvp* out, const float lightPos[4]);
-void vkr_default_lights(vkr_light_uniform* forwardLight, vkr_multiple_lights* braziers);
+VKR_API void vkr_update_depth_mvp_uniforms(vkr_depth_mvp* out, const float lightPos[4]);
+VKR_API void vkr_default_lights(vkr_light_uniform* forwardLight, vkr_multiple_lights* braziers);
 /* Fills every block of `u` for a camera pose and debug mode, as the frame
  * loop does at main/main.cpp:1307-1359. */
-void vkr_make_uniforms(vkr_uniforms* u, uint32_t width, uint32_t height,
+VKR_API void vkr_make_uniforms(vkr_uniforms* u, uint32_t width, uint32_t height,
                        const float camera2world[16], int32_t debugVisualisation);
 
 /* ---- measurement ---- */
@@ -207,14 +213,14 @@ void vkr_make_uniforms(vkr_uniforms* u, uint32_t width, uint32_t height,
 /* Stage timing with HIP events on the context's stream.  Stage names are
  * returned by vkr_stage_name(); times are accumulated per stage since the
  * last vkr_profile_reset(). */
-int vkr_profile_enable(vkr_context* ctx, int on);
-int vkr_profile_reset(vkr_context* ctx);
-int vkr_stage_count(void);
-const char* vkr_stage_name(int stage);
+VKR_API int vkr_profile_enable(vkr_context* ctx, int on);
+VKR_API int vkr_profile_reset(vkr_context* ctx);
+VKR_API int vkr_stage_count(void);
+VKR_API const char* vkr_stage_name(int stage);
 /* Synchronises, then returns accumulated milliseconds and launch count. */
-int vkr_profile_get(vkr_context* ctx, int stage, double* total_ms, uint64_t* launches);
+VKR_API int vkr_profile_get(vkr_context* ctx, int stage, double* total_ms, uint64_t* launches);
 /* The HIP stream (hipStream_t) the context launches on. */
-void* vkr_context_stream(vkr_context* ctx);
+VKR_API void* vkr_context_stream(vkr_context* ctx);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,275 @@
+// k_geometry.hip — vertex transform, triangle setup (clip, cull, snap, depth
+// plane), and screen-tile binning (count -> scan -> fill).
+//
+// Replaces, for every draw of a pass, the vertex shader's
+// gl_Position = projCam * vec4(iPosition,1) (default.vert:85, gBufWrite.vert:70,
+// debug.vert:17, overVisWrite.vert:12, shadowOffscreen.vert:10) and the
+// fixed-function primitive assembly / clipping / culling / viewport stages
+// configured at main/main.cpp:2274-2305 (and :3105-3115 for the shadow pass).
+// Compiled with -ffp-contract=off: the arithmetic order defines coverage.
+#include "vkr_kernels.h"
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_xform(const float* __restrict__ pos, float4* __restrict__ clip, uint32_t nVert, Mat4 M)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= nVert) return;
+	float x = pos[3 * (size_t)v + 0], y = pos[3 * (size_t)v + 1], z = pos[3 * (size_t)v + 2];
+	clip[v] = vkr_xform(M, x, y, z);
+}
+
+// ---------------------------------------------------------------------------
+struct ClipV { double x, y, z, w; };
+
+__device__ __forceinline__ double plane_dist(const ClipV& v, int plane)
+{
+	switch (plane) {
+	case 0: return v.z;
+	case 1: return v.x + VKR_GUARD * v.w;
+	case 2: return VKR_GUARD * v.w - v.x;
+	case 3: return v.y + VKR_GUARD * v.w;
+	default: return VKR_GUARD * v.w - v.y;
+	}
+}
+
+// Sutherland-Hodgman against one plane; new vertices are always interpolated
+// from the inside vertex towards the outside one.
+__device__ __noinline__ int clip_poly(ClipV* v, int n, int plane)
+{
+	double d[10];
+	bool anyOut = false;
+	for (int i = 0; i < n; i++) {
+		d[i] = plane_dist(v[i], plane);
+		if (!(d[i] >= 0.0)) anyOut = true;
+	}
+	if (!anyOut) return n;
+	ClipV o[10];
+	int m = 0;
+	for (int i = 0; i < n; i++) {
+		int j = (i + 1 == n) ? 0 : i + 1;
+		bool ini = d[i] >= 0.0, inj = d[j] >= 0.0;
+		if (ini) o[m++] = v[i];
+		if (ini != inj) {
+			const ClipV A = ini ? v[i] : v[j];
+			const ClipV B = ini ? v[j] : v[i];
+			double dA = ini ? d[i] : d[j], dB = ini ? d[j] : d[i];
+			double t = dA / (dA - dB);
+			ClipV p;
+			p.x = A.x + t * (B.x - A.x);
+			p.y = A.y + t * (B.y - A.y);
+			p.z = A.z + t * (B.z - A.z);
+			p.w = A.w + t * (B.w - A.w);
+			o[m++] = p;
+		}
+	}
+	for (int i = 0; i < m; i++) v[i] = o[i];
+	return m;
+}
+
+__device__ __forceinline__ void snap_vertex(double x, double y, double w, double hW, double hH, int32_t& X, int32_t& Y)
+{
+	double sx = (x / w + 1.0) * hW;
+	double sy = (y / w + 1.0) * hH;
+	X = (int32_t)(long long)floor(sx * (double)VKR_SUBPIX + 0.5);
+	Y = (int32_t)(long long)floor(sy * (double)VKR_SUBPIX + 0.5);
+}
+
+// Finishes one fan triangle: facing, cull, orientation, bounding box, bias,
+// record emission and tile counting.
+__device__ __forceinline__ void emit_subtri(const SetupArgs& a, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2,
+                                            int32_t Y2, const TriPlanes& pl, uint32_t prim, uint32_t flags, int cull)
+{
+	int64_t ax = (int64_t)X1 - X0, ay = (int64_t)Y1 - Y0, bx = (int64_t)X2 - X0, by = (int64_t)Y2 - Y0;
+	int64_t area2 = ax * by - bx * ay;
+	if (area2 == 0) return;
+	bool front = area2 < 0; // Vulkan: a = -area2/2 > 0, frontFace = COUNTER_CLOCKWISE
+	if (cull == 1 && !front) return;
+	if (area2 < 0) { int32_t t = X1; X1 = X2; X2 = t; t = Y1; Y1 = Y2; Y2 = t; }
+	int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
+	int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
+	// pixel centres at p*256+128
+	int32_t px0 = (xmin - 128 + 255) >> 8, px1 = (xmax - 128) >> 8;
+	int32_t py0 = (ymin - 128 + 255) >> 8, py1 = (ymax - 128) >> 8;
+	px0 = max(px0, (int32_t)a.view.x0); py0 = max(py0, (int32_t)a.view.y0);
+	px1 = min(px1, (int32_t)a.view.x1 - 1); py1 = min(py1, (int32_t)a.view.y1 - 1);
+	if (px0 > px1 || py0 > py1) return;
+
+	SubTri r;
+	r.X0 = X0; r.Y0 = Y0; r.X1 = X1; r.Y1 = Y1; r.X2 = X2; r.Y2 = Y2;
+	r.prim = prim;
+	r.flags = flags | (front ? VKR_ST_FRONT : 0u);
+	r.Az = pl.Az; r.Bz = pl.Bz; r.Cz = pl.Cz;
+	r.bias = 0.0;
+	if (a.shadow) {
+		// o = m * slopeFactor + r * constantFactor (main/main.cpp:3112-3114)
+		double m = fabs(pl.Az) > fabs(pl.Bz) ? fabs(pl.Az) : fabs(pl.Bz);
+		double zmax = 0.0;
+		double zv = fma(pl.Az, (double)X0 / 256.0, fma(pl.Bz, (double)Y0 / 256.0, pl.Cz)); if (zv > zmax) zmax = zv;
+		zv = fma(pl.Az, (double)X1 / 256.0, fma(pl.Bz, (double)Y1 / 256.0, pl.Cz)); if (zv > zmax) zmax = zv;
+		zv = fma(pl.Az, (double)X2 / 256.0, fma(pl.Bz, (double)Y2 / 256.0, pl.Cz)); if (zv > zmax) zmax = zv;
+		if (zmax > 1.0) zmax = 1.0;
+		float zmf = (float)zmax;
+		int e = (int)((f2u(zmf) >> 23) & 0xffu) - 127;
+		if (e < -126) e = -126;
+		double rr = __longlong_as_double((long long)(e - 23 + 1023) << 52);
+		r.bias = m * 10.0 + rr * 7.0;
+	}
+	uint32_t slot = atomicAdd(a.recCount, 1u);
+	if (slot >= a.recCap) { atomicOr(a.overflow, 1u); return; }
+	a.recs[slot] = r;
+	uint32_t tx0 = (uint32_t)(px0 - (int32_t)a.view.x0) / VKR_TILE, tx1 = (uint32_t)(px1 - (int32_t)a.view.x0) / VKR_TILE;
+	uint32_t ty0 = (uint32_t)(py0 - (int32_t)a.view.y0) / VKR_TILE, ty1 = (uint32_t)(py1 - (int32_t)a.view.y0) / VKR_TILE;
+	a.recTiles[slot] = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+	for (uint32_t ty = ty0; ty <= ty1; ty++)
+		for (uint32_t tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tileCount[ty * a.view.tilesX + tx], 1u);
+}
+
+__device__ __noinline__ void setup_clipped(const SetupArgs& a, float4 c0, float4 c1, float4 c2, const TriPlanes& pl,
+                                           uint32_t prim, uint32_t flags, int cull, double hW, double hH)
+{
+	ClipV v[10];
+	v[0].x = c0.x; v[0].y = c0.y; v[0].z = c0.z; v[0].w = c0.w;
+	v[1].x = c1.x; v[1].y = c1.y; v[1].z = c1.z; v[1].w = c1.w;
+	v[2].x = c2.x; v[2].y = c2.y; v[2].z = c2.z; v[2].w = c2.w;
+	int n = 3;
+	for (int p = 0; p < 5 && n >= 3; p++) n = clip_poly(v, n, p);
+	if (n < 3) return;
+	int32_t X[10], Y[10];
+	for (int i = 0; i < n; i++) snap_vertex(v[i].x, v[i].y, v[i].w, hW, hH, X[i], Y[i]);
+	for (int i = 1; i + 1 < n; i++) emit_subtri(a, X[0], Y[0], X[i], Y[i], X[i + 1], Y[i + 1], pl, prim, flags, cull);
+}
+
+__global__ __launch_bounds__(256) void k_setup(SetupArgs a)
+{
+	uint32_t t = a.first + blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= a.first + a.count) return;
+	uint32_t i0 = a.sc.tri[3 * (size_t)t + 0], i1 = a.sc.tri[3 * (size_t)t + 1], i2 = a.sc.tri[3 * (size_t)t + 2];
+	float4 c0 = a.clip[i0], c1 = a.clip[i1], c2 = a.clip[i2];
+	// NaN anywhere -> drop
+	if (!(c0.x == c0.x) || !(c0.y == c0.y) || !(c0.z == c0.z) || !(c0.w == c0.w)) return;
+	if (!(c1.x == c1.x) || !(c1.y == c1.y) || !(c1.z == c1.z) || !(c1.w == c1.w)) return;
+	if (!(c2.x == c2.x) || !(c2.y == c2.y) || !(c2.z == c2.z) || !(c2.w == c2.w)) return;
+	// trivial reject against -w<=x,y<=w, 0<=z<=w
+	if ((c0.x < -c0.w) & (c1.x < -c1.w) & (c2.x < -c2.w)) return;
+	if ((c0.x > c0.w) & (c1.x > c1.w) & (c2.x > c2.w)) return;
+	if ((c0.y < -c0.w) & (c1.y < -c1.w) & (c2.y < -c2.w)) return;
+	if ((c0.y > c0.w) & (c1.y > c1.w) & (c2.y > c2.w)) return;
+	if ((c0.z < 0.0f) & (c1.z < 0.0f) & (c2.z < 0.0f)) return;
+	if ((c0.z > c0.w) & (c1.z > c1.w) & (c2.z > c2.w)) return;
+
+	TriPlanes pl;
+	if (!vkr_tri_planes(c0, c1, c2, a.view.W, a.view.H, pl)) return;
+
+	bool isAlphaMesh = t >= a.sc.nTriOpaque;
+	int cull = isAlphaMesh ? a.cullAlpha : a.cullOpaque;
+	uint32_t prim = a.useOrderB ? a.sc.orderB[t] : t;
+	uint32_t flags = 0;
+	if (a.alphaTest && a.sc.mat[a.sc.triMat[t]].alphaTest) flags |= VKR_ST_ALPHA;
+
+	double hW = (double)a.view.W * 0.5, hH = (double)a.view.H * 0.5;
+	// does any vertex violate the near or a guard-band plane?
+	bool needClip = false;
+	{
+		const float4 c[3] = { c0, c1, c2 };
+#pragma unroll
+		for (int i = 0; i < 3; i++) {
+			double x = c[i].x, y = c[i].y, z = c[i].z, w = c[i].w;
+			if (!(z >= 0.0)) needClip = true;
+			if (!(x + VKR_GUARD * w >= 0.0)) needClip = true;
+			if (!(VKR_GUARD * w - x >= 0.0)) needClip = true;
+			if (!(y + VKR_GUARD * w >= 0.0)) needClip = true;
+			if (!(VKR_GUARD * w - y >= 0.0)) needClip = true;
+		}
+	}
+	if (needClip) {
+		setup_clipped(a, c0, c1, c2, pl, prim, flags, cull, hW, hH);
+		return;
+	}
+	int32_t X0, Y0, X1, Y1, X2, Y2;
+	snap_vertex(c0.x, c0.y, c0.w, hW, hH, X0, Y0);
+	snap_vertex(c1.x, c1.y, c1.w, hW, hH, X1, Y1);
+	snap_vertex(c2.x, c2.y, c2.w, hW, hH, X2, Y2);
+	emit_subtri(a, X0, Y0, X1, Y1, X2, Y2, pl, prim, flags, cull);
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan of the per-tile counts (one workgroup), cursor reset
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ count, uint32_t* __restrict__ offset,
+                                                      uint32_t* __restrict__ cursor, uint32_t nTiles, uint32_t cap,
+                                                      uint32_t* overflow)
+{
+	__shared__ uint32_t wsum[16];
+	__shared__ uint32_t carry;
+	uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	if (tid == 0) carry = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < nTiles; base += 1024) {
+		uint32_t i = base + tid;
+		uint32_t v = (i < nTiles) ? count[i] : 0u;
+		uint32_t s = v; // inclusive scan in the wave
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			uint32_t n = __shfl_up(s, d, 64);
+			if ((int)lane >= d) s += n;
+		}
+		if (lane == 63) wsum[wid] = s;
+		__syncthreads();
+		uint32_t wpre = 0;
+		for (uint32_t w = 0; w < wid; w++) wpre += wsum[w];
+		uint32_t excl = carry + wpre + s - v;
+		if (i < nTiles) { offset[i] = excl; cursor[i] = 0; }
+		__syncthreads();
+		if (tid == 1023) carry = excl + v;
+		__syncthreads();
+	}
+	if (tid == 0) {
+		offset[nTiles] = carry;
+		if (carry > cap) atomicOr(overflow, 2u);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
+{
+	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t n = min(*a.recCount, a.recCap);
+	if (r >= n) return;
+	uint2 tr = a.recTiles[r];
+	uint32_t tx0 = tr.x & 0xffffu, ty0 = tr.x >> 16, tx1 = tr.y & 0xffffu, ty1 = tr.y >> 16;
+	uint32_t key = 0;
+	if (a.keys) key = a.recs[r].prim;
+	for (uint32_t ty = ty0; ty <= ty1; ty++)
+		for (uint32_t tx = tx0; tx <= tx1; tx++) {
+			uint32_t tile = ty * a.tilesX + tx;
+			uint32_t idx = a.tileOffset[tile] + atomicAdd(&a.cursor[tile], 1u);
+			if (idx < a.binCap) {
+				a.binList[idx] = r;
+				if (a.keys) a.keys[idx] = key;
+			}
+		}
+}
+
+// ---------------------------------------------------------------------------
+void vkr_launch_xform(hipStream_t s, const float* pos, float4* clip, uint32_t nVert, const Mat4& M)
+{
+	if (!nVert) return;
+	hipLaunchKernelGGL(k_xform, dim3((nVert + 255) / 256), dim3(256), 0, s, pos, clip, nVert, M);
+}
+
+void vkr_launch_setup(hipStream_t s, const SetupArgs& a)
+{
+	if (!a.count) return;
+	hipLaunchKernelGGL(k_setup, dim3((a.count + 255) / 256), dim3(256), 0, s, a);
+}
+
+void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, uint32_t* offset, uint32_t* cursor, uint32_t nTiles,
+                           uint32_t cap, uint32_t* overflow)
+{
+	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, count, offset, cursor, nTiles, cap, overflow);
+}
+
+void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs)
+{
+	if (!maxRecs) return;
+	hipLaunchKernelGGL(k_bin_fill, dim3((maxRecs + 255) / 256), dim3(256), 0, s, a);
+}

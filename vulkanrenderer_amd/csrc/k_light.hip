@@ -1,0 +1,197 @@
+// k_light.hip — full-screen passes: deferred brazier lighting, the overdraw /
+// overshading colour ramp, the mosaic post-process, and mip-chain generation.
+// These produce colour only (parity within 1/255), so this file is compiled
+// with floating-point contraction enabled and uses the hardware's fast
+// reciprocal / rsqrt / exp2.
+#include "vkr_kernels.h"
+
+// ---------------------------------------------------------------------------
+// deferredShading.frag:92-119.  One thread per pixel; reads the two RGBA16F
+// G-buffer attachments and D32 depth (20 B), writes RGBA8 (4 B).  Everything
+// that does not depend on the light is hoisted out of the 21-iteration loop;
+// each light costs two rsqrt, four rcp and one exp2.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ float h2f_lo(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)); }
+__device__ __forceinline__ float h2f_hi(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); }
+
+__global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
+{
+	__shared__ float sThresh[256];
+	if (threadIdx.x < 255) sThresh[threadIdx.x] = a.srgbThresh[threadIdx.x];
+	__syncthreads();
+	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
+	const uint32_t n = rw * rh;
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n) return;
+	const float depth = a.depth[p];
+	if (depth == 1.0f) { a.colour[p] = a.clearColour; return; } // discard: the clear colour stays
+	const uint2 gn = a.gN[p], ga = a.gA[p];
+	const uint32_t x = p % rw, y = p / rw;
+	const float px = (float)(a.view.x0 + x), py = (float)(a.view.y0 + y);
+	// posFromDepth: clip = (uv*2-1, depth, 1); world = (inverse(camera)*inverse(projection)) * clip
+	const float cx = ((px + 0.5f) / (float)a.view.W) * 2.0f - 1.0f;
+	const float cy = ((py + 0.5f) / (float)a.view.H) * 2.0f - 1.0f;
+	float vs[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+		vs[i] = a.invPC.m[0 * 4 + i] * cx + a.invPC.m[1 * 4 + i] * cy + a.invPC.m[2 * 4 + i] * depth + a.invPC.m[3 * 4 + i];
+	const float iw = 1.0f / vs[3];
+	const float Px = vs[0] * iw, Py = vs[1] * iw, Pz = vs[2] * iw;
+	float Vx = a.camPos[0] - Px, Vy = a.camPos[1] - Py, Vz = a.camPos[2] - Pz;
+	{
+		float inv = fast_rsq(Vx * Vx + Vy * Vy + Vz * Vz);
+		Vx *= inv; Vy *= inv; Vz *= inv;
+	}
+	float Nx = h2f_lo(gn.x), Ny = h2f_hi(gn.x), Nz = h2f_lo(gn.y);
+	{
+		float inv = fast_rsq(Nx * Nx + Ny * Ny + Nz * Nz);
+		Nx *= inv; Ny *= inv; Nz *= inv;
+	}
+	const float metal = h2f_hi(gn.y);
+	const float alb[3] = { h2f_lo(ga.x), h2f_hi(ga.x), h2f_lo(ga.y) };
+	const float roughTex = h2f_hi(ga.y);
+	const float rough = roughTex * roughTex;
+	const float r2 = rough * rough;
+	const float PI = 3.14159265359f;
+	const float LOG2E = 1.4426950408889634f;
+	// light-independent terms
+	const float ndv = Nx * Vx + Ny * Vy + Nz * Vz;
+	const float ndvp = fmaxf(ndv, 0.0f);
+	const float pir2 = PI * r2;
+	const float om = 1.0f - metal;
+	float f0[3], omf0[3], kd[3], amb[3];
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+		f0[c] = om * 0.04f + metal * alb[c];
+		omf0[c] = 1.0f - f0[c];
+		kd[c] = (alb[c] / PI) * om;
+		amb[c] = 0.03f * alb[c];
+	}
+	float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll 3
+	for (int i = 0; i < VKR_NUM_LIGHTS_K; i++) {
+		const float Lx0 = a.lightPos[i][0] - Px, Ly0 = a.lightPos[i][1] - Py, Lz0 = a.lightPos[i][2] - Pz;
+		const float d2 = Lx0 * Lx0 + Ly0 * Ly0 + Lz0 * Lz0;
+		const float invd = fast_rsq(d2);
+		const float invd2 = invd * invd;
+		const float Lx = Lx0 * invd, Ly = Ly0 * invd, Lz = Lz0 * invd;
+		float Hx = Vx + Lx, Hy = Vy + Ly, Hz = Vz + Lz;
+		const float invh = fast_rsq(Hx * Hx + Hy * Hy + Hz * Hz);
+		Hx *= invh; Hy *= invh; Hz *= invh;
+		const float ndh = Nx * Hx + Ny * Hy + Nz * Hz;
+		const float ndl = Nx * Lx + Ny * Ly + Nz * Lz;
+		const float vdh = Vx * Hx + Vy * Hy + Vz * Hz;
+		const float ndhp = fmaxf(ndh, 0.0f), ndlp = fmaxf(ndl, 0.0f);
+		// D = exp((nh^2-1)/(r^2 nh^2)) / (0.001 + pi r^2 nh^4)
+		const float nh2 = ndhp * ndhp, nh4 = nh2 * nh2;
+		const float ex = (nh2 - 1.0f) * fast_rcp(r2 * nh2);
+		const float ndf = fast_exp2(ex * LOG2E) * fast_rcp(0.001f + pir2 * nh4);
+		// F = f0 + (1-f0) (1 - v.h)^5
+		const float xx = 1.0f - vdh;
+		const float x2 = xx * xx, x5 = x2 * x2 * xx;
+		// G = min(1, 2 n.h n.v / v.h, 2 n.h n.l / v.h)
+		const float g0 = 2.0f * ndhp * fast_rcp(vdh);
+		const float G = fminf(1.0f, fminf(g0 * ndvp, g0 * ndlp));
+		const float spec = ndf * G * fast_rcp(0.001f + 4.0f * ndvp * ndlp);
+		const float w = 10.0f * ndlp;
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			const float F = f0[c] + omf0[c] * x5;
+			const float br = kd[c] * (1.0f - F) + spec * F;
+			acc[c] += (amb[c] + br * w * a.lightCol[i][c]) * invd2;
+		}
+		acc[3] += invd2;
+	}
+	a.colour[p] = vkr_pack_colour(sThresh, acc[0], acc[1], acc[2], acc[3]);
+}
+
+// overVisRead.frag:7-13: oColor = (0,0.3,0,0.1) + vec4(vec3(stencil/25), 0)
+__global__ __launch_bounds__(256) void k_overvis_colour(const uint8_t* __restrict__ stencil, uint32_t* __restrict__ colour,
+                                                         const float* __restrict__ thresh, uint32_t n)
+{
+	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n) return;
+	float s = (float)stencil[p] / 25.0f;
+	colour[p] = vkr_pack_colour(thresh, 0.0f + s, 0.3f + s, 0.0f + s, 0.1f);
+}
+
+// postProcess.frag:9-25 sampling the offscreen R8G8B8A8_SRGB image
+// (main/main.cpp:1607, 3216) with the default sampler.  src covers the
+// rectangle [srcX0, srcX0+srcW) x [srcY0, srcY0+srcH) of the frame.
+__global__ __launch_bounds__(256) void k_mosaic(const uint32_t* __restrict__ src, uint32_t srcX0, uint32_t srcY0, uint32_t srcW,
+                                                 uint32_t srcH, uint32_t* __restrict__ dst, ViewDev view,
+                                                 const float* __restrict__ decode, const float* __restrict__ thresh)
+{
+	const uint32_t rw = view.x1 - view.x0, rh = view.y1 - view.y0;
+	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+	if (x >= rw || y >= rh) return;
+	const int W = (int)view.W, H = (int)view.H;
+	const float sx = (float)W, sy = (float)H;
+	const float kw = 5.0f / sx, kh = 3.0f / sy;
+	const float ox = 0.5f / sx, oy = 0.5f / sy;
+	const float u = ((float)(view.x0 + x) + 0.5f) / sx, v = ((float)(view.y0 + y) + 0.5f) / sy;
+	float su = kw * floorf(u / kw), sv = kh * floorf(v / kh);
+	su = fminf(fmaxf(su, 0.0f + ox), 1.0f - ox);
+	sv = fminf(fmaxf(sv, 0.0f + oy), 1.0f - oy);
+	const float fxp = su * sx - 0.5f, fyp = sv * sy - 0.5f;
+	const float x0f = floorf(fxp), y0f = floorf(fyp);
+	const float fx = fxp - x0f, fy = fyp - y0f;
+	int x0 = vkr_wrap((int)x0f, W), x1 = vkr_wrap((int)x0f + 1, W);
+	int y0 = vkr_wrap((int)y0f, H), y1 = vkr_wrap((int)y0f + 1, H);
+	// the source rectangle holds every texel a block of this rectangle can touch
+	x0 = min(max(x0 - (int)srcX0, 0), (int)srcW - 1); x1 = min(max(x1 - (int)srcX0, 0), (int)srcW - 1);
+	y0 = min(max(y0 - (int)srcY0, 0), (int)srcH - 1); y1 = min(max(y1 - (int)srcY0, 0), (int)srcH - 1);
+	const uint32_t t00 = src[(size_t)y0 * srcW + x0], t10 = src[(size_t)y0 * srcW + x1];
+	const uint32_t t01 = src[(size_t)y1 * srcW + x0], t11 = src[(size_t)y1 * srcW + x1];
+	float c[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const uint32_t sh = 8u * k;
+		float a00, a10, a01, a11;
+		if (k < 3) {
+			a00 = decode[(t00 >> sh) & 0xffu]; a10 = decode[(t10 >> sh) & 0xffu];
+			a01 = decode[(t01 >> sh) & 0xffu]; a11 = decode[(t11 >> sh) & 0xffu];
+		} else {
+			a00 = (float)(t00 >> 24) / 255.0f; a10 = (float)(t10 >> 24) / 255.0f;
+			a01 = (float)(t01 >> 24) / 255.0f; a11 = (float)(t11 >> 24) / 255.0f;
+		}
+		c[k] = vkr_lerp(vkr_lerp(a00, a10, fx), vkr_lerp(a01, a11, fx), fy);
+	}
+	dst[(size_t)y * rw + x] = vkr_pack_colour(thresh, c[0], c[1], c[2], c[3]);
+}
+
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t* dst, uint32_t value, size_t n)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] = value;
+}
+
+void vkr_launch_deferred_light(hipStream_t s, const LightArgs& a)
+{
+	const uint32_t n = (a.view.x1 - a.view.x0) * (a.view.y1 - a.view.y0);
+	if (!n) return;
+	hipLaunchKernelGGL(k_deferred_light, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+
+void vkr_launch_overvis_colour(hipStream_t s, const uint8_t* stencil, uint32_t* colour, const float* srgbThresh, uint32_t n)
+{
+	if (!n) return;
+	hipLaunchKernelGGL(k_overvis_colour, dim3((n + 255) / 256), dim3(256), 0, s, stencil, colour, srgbThresh, n);
+}
+
+void vkr_launch_mosaic(hipStream_t s, const uint32_t* src, uint32_t srcX0, uint32_t srcY0, uint32_t srcW, uint32_t srcH,
+                       uint32_t* dst, ViewDev view, const float* srgbDecode, const float* srgbThresh)
+{
+	dim3 g((view.x1 - view.x0 + 15) / 16, (view.y1 - view.y0 + 15) / 16);
+	hipLaunchKernelGGL(k_mosaic, g, dim3(256), 0, s, src, srcX0, srcY0, srcW, srcH, dst, view, srgbDecode, srgbThresh);
+}
+
+void vkr_launch_fill_u32(hipStream_t s, uint32_t* dst, uint32_t value, size_t n)
+{
+	if (!n) return;
+	hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, value, n);
+}

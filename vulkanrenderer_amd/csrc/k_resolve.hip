@@ -1,0 +1,275 @@
+// k_resolve.hip — per-pixel shading off the visibility buffer.
+//
+// Each thread takes the (depth | primitive) key of one pixel, rebuilds the
+// triangle's interpolation planes from its clip-space vertices and runs the
+// fragment program of the pass exactly once per visible pixel:
+//   k_resolve_gbuf     gBufWrite.frag:16-27        (deferred geometry subpass)
+//   k_resolve_forward  default.frag:82-104         (forward pass incl. shadow lookup)
+//   k_resolve_debug    debug.frag:19-62            (mip / depth / derivative views)
+// The alpha-test discard of the first two already happened in the rasteriser.
+// Texture LOD uses fine derivatives inside the pixel's 2x2 quad, evaluated on
+// the triangle's own planes (helper-invocation semantics).
+// Compiled with -ffp-contract=off (the mip-level buffer is an integer output).
+#include "vkr_kernels.h"
+
+struct Frag {
+	uint32_t prim;   // submission-order index
+	uint32_t tA;     // index into sc.tri (order A)
+	uint32_t i0, i1, i2;
+	TriPlanes pl;
+	float b[3];
+	float uv[2], d[4];
+	uint32_t mat;
+};
+
+// loads the visible fragment of pixel (px,py); returns false if none
+__device__ __forceinline__ bool load_frag(const ResolveArgs& a, unsigned long long key, int px, int py, uint32_t tA, Frag& f)
+{
+	f.tA = tA;
+	f.i0 = a.sc.tri[3 * (size_t)tA + 0]; f.i1 = a.sc.tri[3 * (size_t)tA + 1]; f.i2 = a.sc.tri[3 * (size_t)tA + 2];
+	if (!vkr_tri_planes(a.clip[f.i0], a.clip[f.i1], a.clip[f.i2], a.view.W, a.view.H, f.pl)) return false;
+	vkr_bary_at(f.pl, px, py, f.b);
+	float2 t0 = make_float2(a.sc.uv[2 * (size_t)f.i0], a.sc.uv[2 * (size_t)f.i0 + 1]);
+	float2 t1 = make_float2(a.sc.uv[2 * (size_t)f.i1], a.sc.uv[2 * (size_t)f.i1 + 1]);
+	float2 t2 = make_float2(a.sc.uv[2 * (size_t)f.i2], a.sc.uv[2 * (size_t)f.i2 + 1]);
+	vkr_uv_derivs(f.pl, px, py, f.b, t0, t1, t2, f.uv, f.d);
+	f.mat = a.sc.triMat[tA];
+	return true;
+}
+
+__device__ __forceinline__ void normalize3(float v[3])
+{
+	float inv = 1.0f / sqrtf(vkr_dot3(v[0], v[1], v[2], v[0], v[1], v[2]));
+	v[0] *= inv; v[1] *= inv; v[2] *= inv;
+}
+
+// normal = v2fTBN * normalize(texture(uNormalMap).rgb*2-1), TBN interpolated per vertex
+__device__ __forceinline__ void shading_normal(const ResolveArgs& a, const Frag& f, const float nm[4], float n[3])
+{
+	float m0[9], m1[9], m2[9];
+	vkr_decode_tbn(a.sc.tcomp[f.i0], m0);
+	vkr_decode_tbn(a.sc.tcomp[f.i1], m1);
+	vkr_decode_tbn(a.sc.tcomp[f.i2], m2);
+	float m[9];
+#pragma unroll
+	for (int i = 0; i < 9; i++) m[i] = vkr_interp(f.b, m0[i], m1[i], m2[i]);
+	float t[3] = { nm[0] * 2.0f - 1.0f, nm[1] * 2.0f - 1.0f, nm[2] * 2.0f - 1.0f };
+	normalize3(t);
+#pragma unroll
+	for (int r = 0; r < 3; r++) n[r] = fmaf(m[6 + r], t[2], fmaf(m[3 + r], t[1], m[0 + r] * t[0]));
+}
+
+__device__ __forceinline__ void decode_key(unsigned long long key, float& depth, uint32_t& prim)
+{
+	depth = u2f((uint32_t)(key >> 32));
+	prim = 0xFFFFFFFEu - (uint32_t)key; // 0xFFFFFFFF when nothing was drawn
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resolve_gbuf(ResolveArgs a)
+{
+	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
+	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+	if (x >= rw || y >= rh) return;
+	const size_t p = (size_t)y * rw + x;
+	const int px = (int)(a.view.x0 + x), py = (int)(a.view.y0 + y);
+	float depth; uint32_t prim;
+	decode_key(a.vis[p], depth, prim);
+	a.depth[p] = depth;
+	if (a.triId) a.triId[p] = prim;
+	// attachment clears 0.1 (main/main.cpp:3843-3851): half(0.1) = 0x2E66
+	uint2 gn = make_uint2(0x2E662E66u, 0x2E662E66u), ga = gn;
+	Frag f;
+	if (prim != VKR_NO_PRIM && load_frag(a, 0, px, py, prim, f)) {
+		const MatInfo& mi = a.sc.mat[f.mat];
+		float nm[4], alb[4], me[4], ro[4], N[3];
+		vkr_trilinear(a.sc, a.sc.tex[mi.tex[4]], f.uv[0], f.uv[1], f.d, nm);
+		vkr_trilinear(a.sc, a.sc.tex[mi.tex[0]], f.uv[0], f.uv[1], f.d, alb);
+		vkr_trilinear(a.sc, a.sc.tex[mi.tex[1]], f.uv[0], f.uv[1], f.d, me);
+		vkr_trilinear(a.sc, a.sc.tex[mi.tex[2]], f.uv[0], f.uv[1], f.d, ro);
+		shading_normal(a, f, nm, N);
+		gn.x = (uint32_t)vkr_f2h(N[0]) | ((uint32_t)vkr_f2h(N[1]) << 16);
+		gn.y = (uint32_t)vkr_f2h(N[2]) | ((uint32_t)vkr_f2h(me[0]) << 16);
+		ga.x = (uint32_t)vkr_f2h(alb[0]) | ((uint32_t)vkr_f2h(alb[1]) << 16);
+		ga.y = (uint32_t)vkr_f2h(alb[2]) | ((uint32_t)vkr_f2h(ro[0]) << 16);
+	}
+	a.gN[p] = gn;
+	a.gA[p] = ga;
+}
+
+// ---------------------------------------------------------------------------
+// BRDF of default.frag:33-80 (forward flavour: nDotH floored at 0.0001)
+__device__ __forceinline__ void brdf_forward(const float L[3], const float V[3], const float N[3], const float albedo[3],
+                                             float metal, float roughTex, float out[3])
+{
+	const float PI = 3.14159265359f;
+	float Hh[3] = { V[0] + L[0], V[1] + L[1], V[2] + L[2] };
+	normalize3(Hh);
+	float rough = roughTex * roughTex;
+	float ndh = vkr_dot3(N[0], N[1], N[2], Hh[0], Hh[1], Hh[2]);
+	float ndv = vkr_dot3(N[0], N[1], N[2], V[0], V[1], V[2]);
+	float ndl = vkr_dot3(N[0], N[1], N[2], L[0], L[1], L[2]);
+	float vdh = vkr_dot3(V[0], V[1], V[2], Hh[0], Hh[1], Hh[2]);
+	float nh = fmaxf(ndh, 0.0001f);
+	float nh2 = nh * nh, nh4 = nh2 * nh2, r2 = rough * rough;
+	float ndf = expf((nh2 - 1.0f) / (r2 * nh2)) / (0.001f + PI * r2 * nh4);
+	float x = 1.0f - vdh;
+	float x2 = x * x, x5 = x2 * x2 * x;
+	float tl = 2.0f * (fmaxf(0.0f, ndh) * fmaxf(0.0f, ndv) / vdh);
+	float tr = 2.0f * (fmaxf(0.0f, ndh) * fmaxf(0.0f, ndl) / vdh);
+	float G = fminf(1.0f, fminf(tl, tr));
+	float denom = 0.001f + 4.0f * fmaxf(ndv, 0.0f) * fmaxf(ndl, 0.0f);
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+		float f0 = (1.0f - metal) * 0.04f + metal * albedo[i];
+		float F = f0 + (1.0f - f0) * x5;
+		float diffuse = (albedo[i] / PI) * (1.0f - F) * (1.0f - metal);
+		out[i] = diffuse + (ndf * F * G) / denom;
+	}
+}
+
+// texture(shadowMap, coord) with the compare sampler of utils/vkutil.cpp:198-217
+__device__ __forceinline__ float shadow_lookup(const float* sm, int S, float u, float v, float ref)
+{
+	float x = u * (float)S - 0.5f, y = v * (float)S - 0.5f;
+	if (!(fabsf(x) < 1.0e9f)) x = 0.0f;
+	if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
+	float x0f = floorf(x), y0f = floorf(y);
+	float fx = x - x0f, fy = y - y0f;
+	int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+	x0 = min(max(x0, 0), S - 1); x1 = min(max(x1, 0), S - 1);
+	y0 = min(max(y0, 0), S - 1); y1 = min(max(y1, 0), S - 1);
+	float t00 = (ref <= sm[(size_t)y0 * S + x0]) ? 1.0f : 0.0f;
+	float t10 = (ref <= sm[(size_t)y0 * S + x1]) ? 1.0f : 0.0f;
+	float t01 = (ref <= sm[(size_t)y1 * S + x0]) ? 1.0f : 0.0f;
+	float t11 = (ref <= sm[(size_t)y1 * S + x1]) ? 1.0f : 0.0f;
+	return vkr_lerp(vkr_lerp(t00, t10, fx), vkr_lerp(t01, t11, fx), fy);
+}
+
+__global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
+{
+	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
+	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+	if (x >= rw || y >= rh) return;
+	const size_t p = (size_t)y * rw + x;
+	const int px = (int)(a.view.x0 + x), py = (int)(a.view.y0 + y);
+	float depth; uint32_t prim;
+	decode_key(a.vis[p], depth, prim);
+	if (a.depth) a.depth[p] = depth;
+	if (a.triId) a.triId[p] = prim;
+	// clear colour (0.1,0.1,0.1,1), main/main.cpp:3988-3991
+	uint32_t colour = vkr_pack_colour(a.sc.srgbThresh, 0.1f, 0.1f, 0.1f, 1.0f);
+	Frag f;
+	if (prim != VKR_NO_PRIM && load_frag(a, 0, px, py, prim, f)) {
+		const MatInfo& mi = a.sc.mat[f.mat];
+		float nm[4], alb[4], me[4], ro[4], N[3], P[3];
+		vkr_trilinear(a.sc, a.sc.tex[mi.tex[4]], f.uv[0], f.uv[1], f.d, nm);
+		vkr_trilinear(a.sc, a.sc.tex[mi.tex[0]], f.uv[0], f.uv[1], f.d, alb);
+		vkr_trilinear(a.sc, a.sc.tex[mi.tex[1]], f.uv[0], f.uv[1], f.d, me);
+		vkr_trilinear(a.sc, a.sc.tex[mi.tex[2]], f.uv[0], f.uv[1], f.d, ro);
+		shading_normal(a, f, nm, N);
+#pragma unroll
+		for (int i = 0; i < 3; i++)
+			P[i] = vkr_interp(f.b, a.sc.pos[3 * (size_t)f.i0 + i], a.sc.pos[3 * (size_t)f.i1 + i], a.sc.pos[3 * (size_t)f.i2 + i]);
+		float Lv[3] = { a.lightPos[0] - P[0], a.lightPos[1] - P[1], a.lightPos[2] - P[2] };
+		float Vv[3] = { a.camPos[0] - P[0], a.camPos[1] - P[1], a.camPos[2] - P[2] };
+		float dist2 = vkr_dot3(Lv[0], Lv[1], Lv[2], Lv[0], Lv[1], Lv[2]);
+		float L[3] = { Lv[0], Lv[1], Lv[2] };
+		normalize3(L);
+		normalize3(Vv);
+		float br[3];
+		brdf_forward(L, Vv, N, alb, me[0], ro[0], br);
+		float ndl = fmaxf(vkr_dot3(N[0], N[1], N[2], L[0], L[1], L[2]), 0.0001f);
+		float att = 1.0f / dist2;
+		float4 ls = vkr_xform(a.lightMat, P[0], P[1], P[2]);
+		float sh = shadow_lookup(a.shadow, (int)a.shadowSize, ls.x / ls.w, ls.y / ls.w, ls.z / ls.w);
+		sh = fmaxf(sh, 0.1f);
+		float c[3];
+#pragma unroll
+		for (int i = 0; i < 3; i++) {
+			float ambient = 0.03f * alb[i];
+			float lit = (br[i] * 100.0f) * a.lightColour[i] * ndl;
+			c[i] = ambient + (lit * sh) * att;
+		}
+		colour = vkr_pack_colour(a.sc.srgbThresh, c[0], c[1], c[2], 1.0f);
+	}
+	a.colour[p] = colour;
+}
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float linearise_depth(float d)
+{
+	return (2.0f * 0.1f * 100.0f) / (100.0f + 0.1f - (2.0f * d - 1.0f) * (100.0f - 0.1f));
+}
+
+__global__ __launch_bounds__(256) void k_resolve_debug(ResolveArgs a)
+{
+	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
+	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+	if (x >= rw || y >= rh) return;
+	const size_t p = (size_t)y * rw + x;
+	const int px = (int)(a.view.x0 + x), py = (int)(a.view.y0 + y);
+	float depth; uint32_t prim;
+	decode_key(a.vis[p], depth, prim);
+	if (a.depth) a.depth[p] = depth;
+	if (a.triId) a.triId[p] = prim;
+	uint32_t colour = vkr_pack_colour(a.sc.srgbThresh, 0.1f, 0.1f, 0.1f, 1.0f); // main/main.cpp:4139-4143
+	uint8_t mip = 0xff;
+	if (prim != VKR_NO_PRIM) {
+		// passes in file order carry the file-order rank; map back to the order-A triangle
+		const uint32_t tA = a.useOrderB ? a.sc.orderB[a.sc.nTri + prim] : prim;
+		Frag f;
+		const int mode = a.debugMode;
+		if (load_frag(a, 0, px, py, tA, f)) {
+			float c[4] = { 0, 0, 0, 1.0f };
+			if (mode == 3) {
+				float v = linearise_depth(depth) / 100.0f;
+				c[0] = c[1] = c[2] = v;
+			} else if (mode == 4) {
+				float zc = linearise_depth(depth);
+				float zx = linearise_depth(vkr_depth_at(f.pl.Az, f.pl.Bz, f.pl.Cz, px ^ 1, py));
+				float zy = linearise_depth(vkr_depth_at(f.pl.Az, f.pl.Bz, f.pl.Cz, px, py ^ 1));
+				float dx = (px & 1) ? (zc - zx) : (zx - zc);
+				float dy = (py & 1) ? (zc - zy) : (zy - zc);
+				c[0] = dx * 5.0f; c[1] = dy * 5.0f; c[2] = 0.0f;
+			} else {
+				const TexInfo& t = a.sc.tex[a.sc.mat[f.mat].tex[0]];
+				int lv; float fr;
+				vkr_lod_split(vkr_rho2(t, f.d), t.levels - 1, lv, fr);
+				mip = (uint8_t)lv;
+				if (mode == 2) {
+					const float col[7][3] = { { 17.0f, 119.0f, 51.0f }, { 136.0f, 34.0f, 85.0f }, { 0.0f, 114.0f, 178.0f },
+						{ 204.0f, 121.0f, 167.0f }, { 0.0f, 158.0f, 115.0f }, { 213.0f, 94.0f, 0.0f }, { 240.0f, 228.0f, 66.0f } };
+					int fl = lv, ce = (fr > 0.0f) ? lv + 1 : lv;
+					float fc = fr;
+					if (fr >= 1.0f) { fl = lv + 1; ce = lv + 1; fc = 0.0f; }
+#pragma unroll
+					for (int i = 0; i < 3; i++) {
+						float ca = col[fl % 7][i] / 255.0f, cb = col[ce % 7][i] / 255.0f;
+						c[i] = ca * (1.0f - fc) + cb * fc;
+					}
+				} else {
+					vkr_trilinear(a.sc, t, f.uv[0], f.uv[1], f.d, c);
+				}
+			}
+			colour = vkr_pack_colour(a.sc.srgbThresh, c[0], c[1], c[2], c[3]);
+		}
+	}
+	a.colour[p] = colour;
+	if (a.mip) a.mip[p] = mip;
+}
+
+static dim3 grid16(const ViewDev& v) { return dim3((v.x1 - v.x0 + 15) / 16, (v.y1 - v.y0 + 15) / 16); }
+
+void vkr_launch_resolve_gbuf(hipStream_t s, const ResolveArgs& a)
+{
+	hipLaunchKernelGGL(k_resolve_gbuf, grid16(a.view), dim3(256), 0, s, a);
+}
+void vkr_launch_resolve_forward(hipStream_t s, const ResolveArgs& a)
+{
+	hipLaunchKernelGGL(k_resolve_forward, grid16(a.view), dim3(256), 0, s, a);
+}
+void vkr_launch_resolve_debug(hipStream_t s, const ResolveArgs& a)
+{
+	hipLaunchKernelGGL(k_resolve_debug, grid16(a.view), dim3(256), 0, s, a);
+}

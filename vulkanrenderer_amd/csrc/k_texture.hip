@@ -1,0 +1,59 @@
+// k_texture.hip — mip-chain generation on the GPU.
+//
+// Replaces the vkCmdBlitImage(..., VK_FILTER_LINEAR) loop of
+// load_image_texture2d (utils/vkimage.cpp:163-216): level n is a linear blit
+// of level n-1 — destination texel centres mapped into source space, bilinear
+// with clamp-to-edge, filtered in linear space for sRGB formats and
+// re-encoded.  Compiled with -ffp-contract=off: texel values feed the alpha
+// test and the integer outputs.
+#include "vkr_kernels.h"
+
+__device__ __forceinline__ void decode_texel(uint32_t p, int srgb, const float* decode, float out[4])
+{
+	if (srgb) {
+		out[0] = decode[p & 0xffu]; out[1] = decode[(p >> 8) & 0xffu]; out[2] = decode[(p >> 16) & 0xffu];
+	} else {
+		out[0] = (float)(p & 0xffu) / 255.0f; out[1] = (float)((p >> 8) & 0xffu) / 255.0f;
+		out[2] = (float)((p >> 16) & 0xffu) / 255.0f;
+	}
+	out[3] = (float)(p >> 24) / 255.0f;
+}
+
+__global__ __launch_bounds__(256) void k_mip_level(uint32_t* texels, uint32_t srcOff, uint32_t sw, uint32_t sh, uint32_t dstOff,
+                                                    uint32_t dw, uint32_t dh, int srgb, const float* __restrict__ decode,
+                                                    const float* __restrict__ thresh)
+{
+	const uint32_t i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
+	if (i >= dw || j >= dh) return;
+	const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
+	const float sv = ((float)j + 0.5f) * scy - 0.5f;
+	const float su = ((float)i + 0.5f) * scx - 0.5f;
+	const float y0f = floorf(sv), x0f = floorf(su);
+	const float fy = sv - y0f, fx = su - x0f;
+	int y0 = (int)y0f, y1 = y0 + 1, x0 = (int)x0f, x1 = x0 + 1;
+	y0 = min(max(y0, 0), (int)sh - 1); y1 = min(max(y1, 0), (int)sh - 1);
+	x0 = min(max(x0, 0), (int)sw - 1); x1 = min(max(x1, 0), (int)sw - 1);
+	const uint32_t* src = texels + srcOff;
+	float t00[4], t10[4], t01[4], t11[4];
+	decode_texel(src[(size_t)y0 * sw + x0], srgb, decode, t00);
+	decode_texel(src[(size_t)y0 * sw + x1], srgb, decode, t10);
+	decode_texel(src[(size_t)y1 * sw + x0], srgb, decode, t01);
+	decode_texel(src[(size_t)y1 * sw + x1], srgb, decode, t11);
+	uint32_t out = 0;
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+		float top = vkr_lerp(t00[c], t10[c], fx);
+		float bot = vkr_lerp(t01[c], t11[c], fx);
+		float v = vkr_lerp(top, bot, fy);
+		uint32_t code = (srgb && c < 3) ? vkr_srgb_encode(thresh, v) : vkr_unorm_encode(v);
+		out |= code << (8 * c);
+	}
+	texels[dstOff + (size_t)j * dw + i] = out;
+}
+
+void vkr_launch_mip_level(hipStream_t s, uint32_t* texels, uint32_t srcOff, uint32_t sw, uint32_t sh, uint32_t dstOff,
+                          uint32_t dw, uint32_t dh, int srgb, const float* srgbDecode, const float* srgbThresh)
+{
+	dim3 g((dw + 15) / 16, (dh + 15) / 16);
+	hipLaunchKernelGGL(k_mip_level, g, dim3(256), 0, s, texels, srcOff, sw, sh, dstOff, dw, dh, srgb, srgbDecode, srgbThresh);
+}

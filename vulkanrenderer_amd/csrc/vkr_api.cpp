@@ -1,0 +1,989 @@
+// vkr_api.cpp — host side of the renderer behind the C ABI of
+// include/vkr_renderer.h: context and scene lifetime, the per-frame mode
+// dispatch that stands in for record_commands() (main/main.cpp:3709-4324),
+// the uniform helpers, stage timing.
+#include "../../include/vkr_renderer.h"
+#include "vkr_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int set_error(int code, const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_CHECK(x)                                                                                        \
+	do {                                                                                                    \
+		hipError_t e_ = (x);                                                                                \
+		if (e_ != hipSuccess) return set_error(VKR_E_DEVICE, "%s failed: %s", #x, hipGetErrorString(e_));   \
+	} while (0)
+
+extern "C" const char* vkr_last_error(void) { return g_err; }
+
+// for the other translation units of the library
+int vkr_set_error_ext(int code, const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+// ---------------------------------------------------------------------------
+// stages
+// ---------------------------------------------------------------------------
+enum Stage {
+	ST_XFORM, ST_SETUP, ST_BIN_SCAN, ST_BIN_FILL, ST_RASTER_VIS, ST_RASTER_SHADOW, ST_RASTER_COUNT, ST_SORT_BINS,
+	ST_OVERSHADE, ST_RESOLVE_GBUF, ST_RESOLVE_FORWARD, ST_RESOLVE_DEBUG, ST_DEFERRED_LIGHT, ST_OVERVIS_COLOUR, ST_MOSAIC,
+	ST_COPY_OUT, ST_COUNT
+};
+static const char* kStageNames[ST_COUNT] = {
+	"k_xform", "k_setup", "k_scan_tiles", "k_bin_fill", "k_raster_vis", "k_raster_shadow", "k_raster_count", "sort_bins",
+	"k_overshade", "k_resolve_gbuf", "k_resolve_forward", "k_resolve_debug", "k_deferred_light", "k_overvis_colour",
+	"k_mosaic", "copy_out"
+};
+
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t bytes)
+	{
+		if (bytes <= cap) return VKR_OK;
+		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		size_t want = bytes + bytes / 8 + 256;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) { p = nullptr; return set_error(VKR_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+		cap = want;
+		return VKR_OK;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <class T> T* as() const { return (T*)p; }
+};
+
+struct Timed { int stage; hipEvent_t a, b; };
+
+struct PendingFrame {
+	const vkr_scene* scene;
+	vkr_frame_params params;
+	vkr_frame_out out;
+	uint32_t statusSlot; // first of the frame's status slots
+	uint32_t nPasses;
+};
+
+struct PassStatus { uint32_t recCount, overflow, binTotal, _pad; };
+
+struct vkr_context {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	float* dDecode = nullptr; // 256
+	float* dThresh = nullptr; // 255
+	float hDecode[256], hThresh[255];
+	// geometry scratch
+	DevBuf clip, recs, recTiles, counters, tileCount, tileOffset, cursor, binList, binKeys, binList2, binKeys2, sortTemp;
+	uint32_t recCap = 0, binCap = 0;
+	double capScale = 1.0;
+	// frame buffers
+	DevBuf vis, depth, triId, gN, gA, colour, colour2, stencil, mip, shadow;
+	// status
+	PassStatus* hStatus = nullptr; // pinned
+	uint32_t statusCap = 0, statusUsed = 0;
+	std::vector<PendingFrame> pending;
+	// profiling
+	bool profiling = false;
+	std::vector<Timed> timed;
+	std::vector<hipEvent_t> eventPool;
+	double stageMs[ST_COUNT] = { 0 };
+	uint64_t stageLaunches[ST_COUNT] = { 0 };
+};
+
+struct HostTex { uint32_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS], off[VKR_MAX_LEVELS]; int levels; int srgb; };
+
+struct vkr_scene {
+	vkr_context* ctx = nullptr;
+	DevBuf pos, uv, tcomp, tri, triMat, orderB, tex, mat, texels;
+	SceneDev dev;
+	std::vector<HostTex> htex;
+	uint64_t nTri = 0, nVert = 0, texelCount = 0;
+};
+
+// ---------------------------------------------------------------------------
+// sRGB tables: decode = EOTF(i/255); thresh[k] = EOTF((k+0.5)/255), both
+// evaluated in double and rounded to float once.
+// ---------------------------------------------------------------------------
+static double srgb_eotf(double c) { return (c <= 0.04045) ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4); }
+
+static uint32_t host_srgb_encode(const float* thresh, float x)
+{
+	if (!(x > 0.0f)) return 0;
+	int lo = 0, hi = 255;
+	while (lo < hi) {
+		int mid = (lo + hi) >> 1;
+		if (x >= thresh[mid]) lo = mid + 1; else hi = mid;
+	}
+	return (uint32_t)lo;
+}
+
+// ---------------------------------------------------------------------------
+// glm-compatible host math (same operation order as glm 1.0.2 so that the
+// uniform blocks equal the reference's bit for bit)
+// ---------------------------------------------------------------------------
+static void mat4_mul(const float a[16], const float b[16], float out[16])
+{
+	float r[16];
+	for (int c = 0; c < 4; c++)
+		for (int i = 0; i < 4; i++) {
+			float t = a[0 * 4 + i] * b[c * 4 + 0];
+			t += a[1 * 4 + i] * b[c * 4 + 1];
+			t += a[2 * 4 + i] * b[c * 4 + 2];
+			t += a[3 * 4 + i] * b[c * 4 + 3];
+			r[c * 4 + i] = t;
+		}
+	memcpy(out, r, sizeof r);
+}
+
+static void mat4_inverse(const float m[16], float out[16])
+{
+	auto M = [&](int c, int r) { return m[c * 4 + r]; };
+	// 2x2 minors of rows 1..3, named by the column pair they skip
+	float s00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3), s02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3), s03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3);
+	float s04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3), s06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3), s07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3);
+	float s08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2), s10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2), s11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2);
+	float s12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3), s14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3), s15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3);
+	float s16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2), s18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2), s19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2);
+	float s20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1), s22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1), s23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+	const float F0[4] = { s00, s00, s02, s03 }, F1[4] = { s04, s04, s06, s07 }, F2[4] = { s08, s08, s10, s11 };
+	const float F3[4] = { s12, s12, s14, s15 }, F4[4] = { s16, s16, s18, s19 }, F5[4] = { s20, s20, s22, s23 };
+	const float V0[4] = { M(1, 0), M(0, 0), M(0, 0), M(0, 0) }, V1[4] = { M(1, 1), M(0, 1), M(0, 1), M(0, 1) };
+	const float V2[4] = { M(1, 2), M(0, 2), M(0, 2), M(0, 2) }, V3[4] = { M(1, 3), M(0, 3), M(0, 3), M(0, 3) };
+	float inv[16];
+	for (int i = 0; i < 4; i++) {
+		const float sgnA = (i & 1) ? -1.0f : 1.0f, sgnB = -sgnA;
+		inv[0 * 4 + i] = ((V1[i] * F0[i] - V2[i] * F1[i]) + V3[i] * F2[i]) * sgnA;
+		inv[1 * 4 + i] = ((V0[i] * F0[i] - V2[i] * F3[i]) + V3[i] * F4[i]) * sgnB;
+		inv[2 * 4 + i] = ((V0[i] * F1[i] - V1[i] * F3[i]) + V3[i] * F5[i]) * sgnA;
+		inv[3 * 4 + i] = ((V0[i] * F2[i] - V1[i] * F4[i]) + V2[i] * F5[i]) * sgnB;
+	}
+	const float det = (M(0, 0) * inv[0] + M(0, 1) * inv[4]) + (M(0, 2) * inv[8] + M(0, 3) * inv[12]);
+	const float ood = 1.0f / det;
+	for (int i = 0; i < 16; i++) out[i] = inv[i] * ood;
+}
+
+static void perspective_rh_zo(float fovy, float aspect, float zn, float zf, float out[16])
+{
+	const float th = tanf(fovy / 2.0f);
+	memset(out, 0, sizeof(float) * 16);
+	out[0] = 1.0f / (aspect * th);
+	out[5] = 1.0f / th;
+	out[10] = zf / (zn - zf);
+	out[11] = -1.0f;
+	out[14] = -(zf * zn) / (zf - zn);
+}
+
+static float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void norm3(const float a[3], float o[3])
+{
+	const float inv = 1.0f / sqrtf(dot3(a, a));
+	o[0] = a[0] * inv; o[1] = a[1] * inv; o[2] = a[2] * inv;
+}
+static void cross3(const float x[3], const float y[3], float o[3])
+{
+	o[0] = x[1] * y[2] - y[1] * x[2];
+	o[1] = x[2] * y[0] - y[2] * x[0];
+	o[2] = x[0] * y[1] - y[0] * x[1];
+}
+
+static void look_at_rh(const float eye[3], const float center[3], const float up[3], float out[16])
+{
+	float d[3] = { center[0] - eye[0], center[1] - eye[1], center[2] - eye[2] }, f[3], s[3], u[3], t[3];
+	norm3(d, f);
+	cross3(f, up, t);
+	norm3(t, s);
+	cross3(s, f, u);
+	memset(out, 0, sizeof(float) * 16);
+	out[15] = 1.0f;
+	out[0] = s[0]; out[4] = s[1]; out[8] = s[2];
+	out[1] = u[0]; out[5] = u[1]; out[9] = u[2];
+	out[2] = -f[0]; out[6] = -f[1]; out[10] = -f[2];
+	out[12] = -dot3(s, eye); out[13] = -dot3(u, eye); out[14] = dot3(f, eye);
+}
+
+extern "C" void vkr_update_scene_uniforms(vkr_scene_uniform* u, uint32_t width, uint32_t height, const float camera2world[16])
+{
+	// main/main.cpp:3681-3693; kCameraFov 60 deg -> rad as utils/angle.hpp:11-14, near/far main/main.cpp:75-76
+	const float pi = 3.14159265358979323846f;
+	const float fov = 60.0f * pi / 180.0f;
+	const float aspect = (float)width / (float)height;
+	perspective_rh_zo(fov, aspect, 0.1f, 100.0f, u->projection);
+	u->projection[5] *= -1.0f;
+	mat4_inverse(camera2world, u->camera);
+	mat4_mul(u->projection, u->camera, u->projCam);
+	u->camPos[0] = camera2world[12]; u->camPos[1] = camera2world[13]; u->camPos[2] = camera2world[14]; u->camPos[3] = 1.0f;
+}
+
+extern "C" void vkr_update_depth_mvp_uniforms(vkr_depth_mvp* d, const float lightPos[4])
+{
+	// main/main.cpp:3699-3707.  lut::Radians(90.0f) is 90 radians (utils/angle.hpp:65), kept as is.
+	float proj[16], view[16];
+	perspective_rh_zo(90.0f, 1.0f, 0.1f, 100.0f, proj);
+	proj[5] *= -1.0f;
+	const float eye[3] = { lightPos[0], lightPos[1], lightPos[2] }, center[3] = { 0.0f, 0.0f, -48.0f }, up[3] = { 0.0f, 1.0f, 0.0f };
+	look_at_rh(eye, center, up, view);
+	mat4_mul(proj, view, d->depthMVP);
+}
+
+extern "C" void vkr_default_lights(vkr_light_uniform* fwd, vkr_multiple_lights* ml)
+{
+	// main/main.cpp:1313-1352
+	static const float P[VKR_NUM_LIGHTS][3] = {
+		{ 8.0377f, -1.1000f, -15.8845f }, { 5.6632f, -1.1000f, -12.2500f }, { 2.1255f, -1.1000f, -10.1000f },
+		{ -2.0867f, -1.1000f, -10.2500f }, { -5.7367f, -1.1000f, -12.2000f }, { -7.8244f, -1.1000f, -15.8500f },
+		{ 3.0632f, -1.1000f, -25.8500f }, { -3.0632f, -1.1000f, -25.8500f }, { -7.4867f, -1.1000f, -36.0500f },
+		{ -2.4367f, -3.1000f, -46.5500f }, { 2.3632f, -3.1000f, -46.5500f }, { -0.0514f, -3.9000f, -49.6000f },
+		{ -7.2367f, -3.1000f, -61.2500f }, { 7.1088f, -3.1000f, -61.2500f }, { -2.0867f, -3.1000f, -66.5500f },
+		{ 2.0867f, -3.1000f, -66.5500f }, { -2.0867f, -3.1000f, -68.9000f }, { 2.0867f, -3.1000f, -68.9000f },
+		{ 0.0000f, -4.1000f, -76.0000f }, { -1.6867f, -3.1000f, -88.8500f }, { 1.6867f, -3.1000f, -88.8500f } };
+	if (fwd) {
+		fwd->lightPos[0] = -0.2972f; fwd->lightPos[1] = 7.3100f; fwd->lightPos[2] = -11.9532f; fwd->lightPos[3] = 0.0f;
+		for (int i = 0; i < 4; i++) fwd->lightColour[i] = 1.0f;
+	}
+	if (ml)
+		for (int i = 0; i < VKR_NUM_LIGHTS; i++) {
+			for (int k = 0; k < 3; k++) ml->light[i].lightPos[k] = P[i][k];
+			ml->light[i].lightPos[3] = 0.0f;
+			ml->light[i].lightColour[0] = 0.9882f; ml->light[i].lightColour[1] = 0.4549f;
+			ml->light[i].lightColour[2] = 0.0196f; ml->light[i].lightColour[3] = 1.0f;
+		}
+}
+
+extern "C" void vkr_make_uniforms(vkr_uniforms* u, uint32_t width, uint32_t height, const float camera2world[16], int32_t debug)
+{
+	memset(u, 0, sizeof *u);
+	vkr_update_scene_uniforms(&u->sceneUniforms, width, height, camera2world);
+	u->debugUniforms.debug = debug;
+	vkr_default_lights(&u->lightUniforms, &u->multipleLightsUniform);
+	vkr_update_depth_mvp_uniforms(&u->depthMVPUniform, u->lightUniforms.lightPos);
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" int vkr_context_create(int device, vkr_context** out)
+{
+	if (!out) return set_error(VKR_E_INVALID, "vkr_context_create: out is NULL");
+	*out = nullptr;
+	int count = 0;
+	HIP_CHECK(hipGetDeviceCount(&count));
+	if (device < 0 || device >= count) return set_error(VKR_E_INVALID, "vkr_context_create: device %d of %d", device, count);
+	HIP_CHECK(hipSetDevice(device));
+	vkr_context* c = new (std::nothrow) vkr_context();
+	if (!c) return set_error(VKR_E_NOMEM, "out of host memory");
+	c->device = device;
+	for (int i = 0; i < 256; i++) c->hDecode[i] = (float)srgb_eotf((double)i / 255.0);
+	for (int i = 0; i < 255; i++) c->hThresh[i] = (float)srgb_eotf(((double)i + 0.5) / 255.0);
+	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipMalloc((void**)&c->dDecode, 256 * sizeof(float));
+	if (e == hipSuccess) e = hipMalloc((void**)&c->dThresh, 256 * sizeof(float));
+	if (e == hipSuccess) e = hipMemcpy(c->dDecode, c->hDecode, 256 * sizeof(float), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(c->dThresh, c->hThresh, 255 * sizeof(float), hipMemcpyHostToDevice);
+	if (e != hipSuccess) {
+		int rc = set_error(VKR_E_DEVICE, "vkr_context_create: %s", hipGetErrorString(e));
+		vkr_context_destroy(c);
+		return rc;
+	}
+	*out = c;
+	return VKR_OK;
+}
+
+extern "C" void vkr_context_destroy(vkr_context* c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	DevBuf* bufs[] = { &c->clip, &c->recs, &c->recTiles, &c->counters, &c->tileCount, &c->tileOffset, &c->cursor, &c->binList,
+		&c->binKeys, &c->binList2, &c->binKeys2, &c->sortTemp, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
+		&c->colour2, &c->stencil, &c->mip, &c->shadow };
+	for (DevBuf* b : bufs) b->release();
+	for (auto& t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+	for (auto e : c->eventPool) (void)hipEventDestroy(e);
+	if (c->hStatus) (void)hipHostFree(c->hStatus);
+	if (c->dDecode) (void)hipFree(c->dDecode);
+	if (c->dThresh) (void)hipFree(c->dThresh);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" void* vkr_context_stream(vkr_context* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------
+static hipEvent_t get_event(vkr_context* c)
+{
+	if (!c->eventPool.empty()) { hipEvent_t e = c->eventPool.back(); c->eventPool.pop_back(); return e; }
+	hipEvent_t e = nullptr;
+	(void)hipEventCreate(&e);
+	return e;
+}
+
+struct StageTimer {
+	vkr_context* c; Timed t; bool on;
+	StageTimer(vkr_context* ctx, int stage) : c(ctx), on(ctx->profiling)
+	{
+		if (!on) return;
+		t.stage = stage; t.a = get_event(c); t.b = get_event(c);
+		(void)hipEventRecord(t.a, c->stream);
+	}
+	~StageTimer()
+	{
+		if (!on) return;
+		(void)hipEventRecord(t.b, c->stream);
+		c->timed.push_back(t);
+	}
+};
+
+static void drain_timers(vkr_context* c)
+{
+	for (auto& t : c->timed) {
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { c->stageMs[t.stage] += ms; c->stageLaunches[t.stage]++; }
+		c->eventPool.push_back(t.a); c->eventPool.push_back(t.b);
+	}
+	c->timed.clear();
+}
+
+extern "C" int vkr_profile_enable(vkr_context* c, int on)
+{
+	if (!c) return set_error(VKR_E_INVALID, "NULL context");
+	c->profiling = on != 0;
+	return VKR_OK;
+}
+extern "C" int vkr_profile_reset(vkr_context* c)
+{
+	if (!c) return set_error(VKR_E_INVALID, "NULL context");
+	HIP_CHECK(hipSetDevice(c->device));
+	HIP_CHECK(hipStreamSynchronize(c->stream));
+	drain_timers(c);
+	for (int i = 0; i < ST_COUNT; i++) { c->stageMs[i] = 0; c->stageLaunches[i] = 0; }
+	return VKR_OK;
+}
+extern "C" int vkr_stage_count(void) { return ST_COUNT; }
+extern "C" const char* vkr_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
+extern "C" int vkr_profile_get(vkr_context* c, int stage, double* ms, uint64_t* launches)
+{
+	if (!c || stage < 0 || stage >= ST_COUNT) return set_error(VKR_E_INVALID, "bad stage");
+	HIP_CHECK(hipSetDevice(c->device));
+	HIP_CHECK(hipStreamSynchronize(c->stream));
+	drain_timers(c);
+	if (ms) *ms = c->stageMs[stage];
+	if (launches) *launches = c->stageLaunches[stage];
+	return VKR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// scene
+// ---------------------------------------------------------------------------
+static int mip_level_count(uint32_t w, uint32_t h)
+{
+	uint32_t bits = w | h; // compute_mip_level_count, utils/vkimage.cpp:289-294
+	int n = 0;
+	while (bits) { n++; bits >>= 1; }
+	return n;
+}
+
+extern "C" void vkr_scene_destroy(vkr_scene* s)
+{
+	if (!s) return;
+	if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
+	DevBuf* bufs[] = { &s->pos, &s->uv, &s->tcomp, &s->tri, &s->triMat, &s->orderB, &s->tex, &s->mat, &s->texels };
+	for (DevBuf* b : bufs) b->release();
+	delete s;
+}
+
+extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_scene** out)
+{
+	if (!c || !d || !out) return set_error(VKR_E_INVALID, "vkr_scene_create: NULL argument");
+	*out = nullptr;
+	HIP_CHECK(hipSetDevice(c->device));
+	// ---- validate
+	for (uint32_t i = 0; i < d->textureCount; i++) {
+		const vkr_texture_desc& t = d->textures[i];
+		if (!t.rgba8 || t.width == 0 || t.height == 0 || t.width > 32768 || t.height > 32768)
+			return set_error(VKR_E_INVALID, "texture %u: bad size %ux%u or NULL data", i, t.width, t.height);
+	}
+	for (uint32_t i = 0; i < d->materialCount; i++) {
+		const vkr_material_desc& m = d->materials[i];
+		// main/baked_model.cpp:126-129 asserts these; the normal map has no fallback (main/main.cpp:770-846)
+		if (m.baseColorTextureId >= d->textureCount || m.roughnessTextureId >= d->textureCount ||
+		    m.metalnessTextureId >= d->textureCount || m.normalMapTextureId >= d->textureCount)
+			return set_error(VKR_E_INVALID, "material %u names a texture outside [0,%u)", i, d->textureCount);
+		if (m.alphaMaskTextureId != VKR_NO_TEXTURE && m.alphaMaskTextureId >= d->textureCount)
+			return set_error(VKR_E_INVALID, "material %u: alpha mask texture %u out of range", i, m.alphaMaskTextureId);
+	}
+	uint64_t nVert = 0, nTri = 0, nTriOpaque = 0;
+	for (uint32_t i = 0; i < d->meshCount; i++) {
+		const vkr_mesh_desc& m = d->meshes[i];
+		if (m.materialId >= d->materialCount) return set_error(VKR_E_INVALID, "mesh %u: material %u out of range", i, m.materialId);
+		if (m.indexCount % 3) return set_error(VKR_E_INVALID, "mesh %u: index count %u is not a multiple of 3", i, m.indexCount);
+		if (m.vertexCount && (!m.positions || !m.texcoords || !m.tangentsComp)) return set_error(VKR_E_INVALID, "mesh %u: NULL vertex array", i);
+		if (m.indexCount && !m.indices) return set_error(VKR_E_INVALID, "mesh %u: NULL index array", i);
+		for (uint32_t k = 0; k < m.indexCount; k++)
+			if (m.indices[k] >= m.vertexCount) return set_error(VKR_E_INVALID, "mesh %u: index %u = %u >= vertexCount %u", i, k, m.indices[k], m.vertexCount);
+		nVert += m.vertexCount;
+		nTri += m.indexCount / 3;
+		if (d->materials[m.materialId].alphaMaskTextureId == VKR_NO_TEXTURE) nTriOpaque += m.indexCount / 3;
+	}
+	if (nVert >= 0xfffffff0ull || nTri >= 0x1fffffffull) return set_error(VKR_E_LIMIT, "scene too large (%llu vertices, %llu triangles)", (unsigned long long)nVert, (unsigned long long)nTri);
+
+	vkr_scene* s = new (std::nothrow) vkr_scene();
+	if (!s) return set_error(VKR_E_NOMEM, "out of host memory");
+	s->ctx = c; s->nTri = nTri; s->nVert = nVert;
+	int rc = VKR_OK;
+	auto fail = [&](int code) { vkr_scene_destroy(s); return code; };
+
+	// ---- geometry: vertices concatenated in file order; triangles in
+	// submission order A = opaque meshes first, then alpha-masked meshes
+	// (main/main.cpp:1080-1081, 3873-3934)
+	std::vector<float> pos(3 * nVert), uv(2 * nVert);
+	std::vector<uint32_t> tcomp(nVert), tri(3 * nTri), triMat(nTri), orderB(2 * nTri);
+	std::vector<uint64_t> vbase(d->meshCount), tbaseB(d->meshCount);
+	{
+		uint64_t v = 0, t = 0;
+		for (uint32_t i = 0; i < d->meshCount; i++) {
+			const vkr_mesh_desc& m = d->meshes[i];
+			vbase[i] = v; tbaseB[i] = t;
+			if (m.vertexCount) {
+				memcpy(&pos[3 * v], m.positions, sizeof(float) * 3 * m.vertexCount);
+				memcpy(&uv[2 * v], m.texcoords, sizeof(float) * 2 * m.vertexCount);
+				memcpy(&tcomp[v], m.tangentsComp, sizeof(uint32_t) * m.vertexCount);
+			}
+			v += m.vertexCount; t += m.indexCount / 3;
+		}
+		uint64_t a = 0;
+		for (int pass = 0; pass < 2; pass++)
+			for (uint32_t i = 0; i < d->meshCount; i++) {
+				const vkr_mesh_desc& m = d->meshes[i];
+				const int isAlpha = d->materials[m.materialId].alphaMaskTextureId != VKR_NO_TEXTURE;
+				if (isAlpha != pass) continue;
+				for (uint32_t k = 0; k < m.indexCount / 3; k++, a++) {
+					tri[3 * a + 0] = (uint32_t)(vbase[i] + m.indices[3 * k + 0]);
+					tri[3 * a + 1] = (uint32_t)(vbase[i] + m.indices[3 * k + 1]);
+					tri[3 * a + 2] = (uint32_t)(vbase[i] + m.indices[3 * k + 2]);
+					triMat[a] = m.materialId;
+					const uint32_t b = (uint32_t)(tbaseB[i] + k);
+					orderB[a] = b;                 // A -> file-order rank
+					orderB[nTri + b] = (uint32_t)a; // file-order rank -> A
+				}
+			}
+	}
+	auto upload = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+		int r = b.ensure(bytes ? bytes : 4);
+		if (r) return r;
+		if (bytes) {
+			hipError_t e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+			if (e != hipSuccess) return set_error(VKR_E_DEVICE, "scene upload: %s", hipGetErrorString(e));
+		}
+		return VKR_OK;
+	};
+	if ((rc = upload(s->pos, pos.data(), pos.size() * 4))) return fail(rc);
+	if ((rc = upload(s->uv, uv.data(), uv.size() * 4))) return fail(rc);
+	if ((rc = upload(s->tcomp, tcomp.data(), tcomp.size() * 4))) return fail(rc);
+	if ((rc = upload(s->tri, tri.data(), tri.size() * 4))) return fail(rc);
+	if ((rc = upload(s->triMat, triMat.data(), triMat.size() * 4))) return fail(rc);
+	if ((rc = upload(s->orderB, orderB.data(), orderB.size() * 4))) return fail(rc);
+
+	// ---- textures: one texel pool, level 0 uploaded, levels 1.. built on the GPU
+	std::vector<TexInfo> tinfo(d->textureCount ? d->textureCount : 1);
+	s->htex.resize(d->textureCount);
+	uint64_t texels = 0;
+	for (uint32_t i = 0; i < d->textureCount; i++) {
+		const vkr_texture_desc& t = d->textures[i];
+		HostTex& h = s->htex[i];
+		h.levels = mip_level_count(t.width, t.height);
+		h.srgb = t.space == 1;
+		uint32_t w = t.width, hh = t.height;
+		memset(&tinfo[i], 0, sizeof(TexInfo));
+		for (int l = 0; l < h.levels; l++) {
+			h.w[l] = w; h.h[l] = hh; h.off[l] = (uint32_t)texels;
+			tinfo[i].offset[l] = (uint32_t)texels; tinfo[i].w[l] = (uint16_t)w; tinfo[i].h[l] = (uint16_t)hh;
+			texels += (uint64_t)w * hh;
+			w >>= 1; if (!w) w = 1;
+			hh >>= 1; if (!hh) hh = 1;
+		}
+		tinfo[i].levels = h.levels; tinfo[i].srgb = h.srgb;
+		if (texels >= 0xffffffffull) return fail(set_error(VKR_E_LIMIT, "texel pool exceeds 2^32 texels"));
+	}
+	s->texelCount = texels;
+	if ((rc = s->texels.ensure(texels ? texels * 4 : 4))) return fail(rc);
+	for (uint32_t i = 0; i < d->textureCount; i++) {
+		const vkr_texture_desc& t = d->textures[i];
+		hipError_t e = hipMemcpyAsync(s->texels.as<uint32_t>() + s->htex[i].off[0], t.rgba8, (size_t)t.width * t.height * 4,
+		                              hipMemcpyHostToDevice, c->stream);
+		if (e != hipSuccess) return fail(set_error(VKR_E_DEVICE, "texture upload: %s", hipGetErrorString(e)));
+		for (int l = 1; l < s->htex[i].levels; l++)
+			vkr_launch_mip_level(c->stream, s->texels.as<uint32_t>(), s->htex[i].off[l - 1], s->htex[i].w[l - 1], s->htex[i].h[l - 1],
+			                     s->htex[i].off[l], s->htex[i].w[l], s->htex[i].h[l], s->htex[i].srgb, c->dDecode, c->dThresh);
+	}
+	if ((rc = upload(s->tex, tinfo.data(), tinfo.size() * sizeof(TexInfo)))) return fail(rc);
+
+	// ---- materials: binding table + whether the alpha test can ever discard
+	std::vector<int> lowAlpha(d->textureCount, -1);
+	std::vector<MatInfo> minfo(d->materialCount ? d->materialCount : 1);
+	for (uint32_t i = 0; i < d->materialCount; i++) {
+		const vkr_material_desc& m = d->materials[i];
+		MatInfo& mi = minfo[i];
+		memset(&mi, 0, sizeof mi);
+		mi.tex[0] = m.baseColorTextureId;
+		mi.tex[1] = m.metalnessTextureId; // binding 1
+		mi.tex[2] = m.roughnessTextureId; // binding 2
+		mi.tex[3] = (m.alphaMaskTextureId == VKR_NO_TEXTURE) ? m.baseColorTextureId : m.alphaMaskTextureId; // main/main.cpp:812-817
+		mi.tex[4] = m.normalMapTextureId;
+		const uint32_t at = mi.tex[3];
+		if (lowAlpha[at] < 0) {
+			// filtered alpha is a convex combination of texel alphas (mips included), so it can
+			// fall below 0.5 only if some level-0 texel is below 128/255
+			const vkr_texture_desc& t = d->textures[at];
+			int low = 0;
+			const size_t n = (size_t)t.width * t.height;
+			for (size_t k = 0; k < n; k++) if (t.rgba8[4 * k + 3] < 128) { low = 1; break; }
+			lowAlpha[at] = low;
+		}
+		mi.alphaTest = (uint32_t)lowAlpha[at];
+	}
+	if ((rc = upload(s->mat, minfo.data(), minfo.size() * sizeof(MatInfo)))) return fail(rc);
+	{
+		hipError_t e = hipStreamSynchronize(c->stream);
+		if (e != hipSuccess) return fail(set_error(VKR_E_DEVICE, "mip generation: %s", hipGetErrorString(e)));
+	}
+	SceneDev& dv = s->dev;
+	dv.pos = s->pos.as<float>(); dv.uv = s->uv.as<float>(); dv.tcomp = s->tcomp.as<uint32_t>();
+	dv.tri = s->tri.as<uint32_t>(); dv.triMat = s->triMat.as<uint32_t>(); dv.orderB = s->orderB.as<uint32_t>();
+	dv.tex = s->tex.as<TexInfo>(); dv.mat = s->mat.as<MatInfo>(); dv.texels = s->texels.as<uint32_t>();
+	dv.srgbDecode = c->dDecode; dv.srgbThresh = c->dThresh;
+	dv.nTri = (uint32_t)nTri; dv.nTriOpaque = (uint32_t)nTriOpaque; dv.nVert = (uint32_t)nVert;
+	dv.nTex = d->textureCount; dv.nMat = d->materialCount;
+	*out = s;
+	return VKR_OK;
+}
+
+extern "C" int vkr_scene_stats(const vkr_scene* s, uint64_t* triangles, uint64_t* vertices, uint64_t* texture_bytes)
+{
+	if (!s) return set_error(VKR_E_INVALID, "NULL scene");
+	if (triangles) *triangles = s->nTri;
+	if (vertices) *vertices = s->nVert;
+	if (texture_bytes) *texture_bytes = s->texelCount * 4;
+	return VKR_OK;
+}
+
+extern "C" int vkr_scene_read_texture_level(const vkr_scene* s, uint32_t tex, uint32_t level, uint8_t* out, uint32_t* w, uint32_t* h)
+{
+	if (!s || tex >= s->htex.size() || (int)level >= s->htex[tex].levels) return set_error(VKR_E_INVALID, "no such texture level");
+	const HostTex& t = s->htex[tex];
+	if (w) *w = t.w[level];
+	if (h) *h = t.h[level];
+	if (out) {
+		HIP_CHECK(hipSetDevice(s->ctx->device));
+		HIP_CHECK(hipMemcpy(out, s->texels.as<uint32_t>() + t.off[level], (size_t)t.w[level] * t.h[level] * 4, hipMemcpyDeviceToHost));
+	}
+	return VKR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// frame
+// ---------------------------------------------------------------------------
+static ViewDev make_view(uint32_t W, uint32_t H, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
+{
+	ViewDev v;
+	v.W = W; v.H = H; v.x0 = x0; v.y0 = y0; v.x1 = x1; v.y1 = y1;
+	v.tilesX = (x1 - x0 + VKR_TILE - 1) / VKR_TILE;
+	v.tilesY = (y1 - y0 + VKR_TILE - 1) / VKR_TILE;
+	return v;
+}
+
+static int ensure_status(vkr_context* c, uint32_t need)
+{
+	if (c->statusUsed + need <= c->statusCap) return VKR_OK;
+	// only grows while nothing is pending
+	if (!c->pending.empty()) return set_error(VKR_E_LIMIT, "too many frames in flight without vkr_wait (%zu)", c->pending.size());
+	uint32_t cap = c->statusCap ? c->statusCap * 2 : 4096;
+	while (cap < need) cap *= 2;
+	if (c->hStatus) (void)hipHostFree(c->hStatus);
+	c->hStatus = nullptr; c->statusCap = 0; c->statusUsed = 0;
+	HIP_CHECK(hipHostMalloc((void**)&c->hStatus, sizeof(PassStatus) * cap, hipHostMallocDefault));
+	c->statusCap = cap;
+	return VKR_OK;
+}
+
+struct GeomPass {
+	Mat4 M; ViewDev view; uint32_t first, count; int cullOpaque, cullAlpha, useOrderB, alphaTest, shadow; bool keys;
+};
+
+// transform -> setup -> bin for one pass; leaves recs / tileOffset / binList ready
+static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, uint32_t statusSlot)
+{
+	const uint32_t nTiles = g.view.tilesX * g.view.tilesY;
+	if (nTiles == 0 || nTiles > (1u << 24)) return set_error(VKR_E_LIMIT, "tile count %u out of range", nTiles);
+	const uint32_t recCap = (uint32_t)std::min<double>(4.0e9, ((double)g.count * 1.25 + 4096.0) * c->capScale);
+	const uint32_t binCap = (uint32_t)std::min<double>(4.0e9, ((double)recCap * 3.0 + nTiles) * c->capScale);
+	int rc;
+	if ((rc = c->clip.ensure((size_t)s->dev.nVert * sizeof(float4)))) return rc;
+	if ((rc = c->recs.ensure((size_t)recCap * sizeof(SubTri)))) return rc;
+	if ((rc = c->recTiles.ensure((size_t)recCap * sizeof(uint2)))) return rc;
+	if ((rc = c->counters.ensure(64))) return rc;
+	if ((rc = c->tileCount.ensure((size_t)nTiles * 4))) return rc;
+	if ((rc = c->tileOffset.ensure((size_t)(nTiles + 1) * 4))) return rc;
+	if ((rc = c->cursor.ensure((size_t)nTiles * 4))) return rc;
+	if ((rc = c->binList.ensure((size_t)binCap * 4))) return rc;
+	if (g.keys && (rc = c->binKeys.ensure((size_t)binCap * 4))) return rc;
+	c->recCap = recCap; c->binCap = binCap;
+	uint32_t* counters = c->counters.as<uint32_t>(); // [0] recCount, [1] overflow
+	HIP_CHECK(hipMemsetAsync(counters, 0, 64, c->stream));
+	HIP_CHECK(hipMemsetAsync(c->tileCount.p, 0, (size_t)nTiles * 4, c->stream));
+	{
+		StageTimer t(c, ST_XFORM);
+		vkr_launch_xform(c->stream, s->dev.pos, c->clip.as<float4>(), s->dev.nVert, g.M);
+	}
+	{
+		StageTimer t(c, ST_SETUP);
+		SetupArgs a;
+		a.sc = s->dev; a.view = g.view; a.clip = c->clip.as<float4>();
+		a.first = g.first; a.count = g.count; a.cullOpaque = g.cullOpaque; a.cullAlpha = g.cullAlpha;
+		a.useOrderB = g.useOrderB; a.alphaTest = g.alphaTest; a.shadow = g.shadow;
+		a.recs = c->recs.as<SubTri>(); a.recTiles = c->recTiles.as<uint2>(); a.recCap = recCap;
+		a.recCount = counters; a.tileCount = c->tileCount.as<uint32_t>(); a.overflow = counters + 1;
+		vkr_launch_setup(c->stream, a);
+	}
+	{
+		StageTimer t(c, ST_BIN_SCAN);
+		vkr_launch_scan_tiles(c->stream, c->tileCount.as<uint32_t>(), c->tileOffset.as<uint32_t>(), c->cursor.as<uint32_t>(), nTiles,
+		                      binCap, counters + 1);
+	}
+	{
+		StageTimer t(c, ST_BIN_FILL);
+		BinFillArgs b;
+		b.recs = c->recs.as<SubTri>(); b.recTiles = c->recTiles.as<uint2>(); b.recCount = counters; b.recCap = recCap;
+		b.tileOffset = c->tileOffset.as<uint32_t>(); b.cursor = c->cursor.as<uint32_t>(); b.binList = c->binList.as<uint32_t>();
+		b.keys = g.keys ? c->binKeys.as<uint32_t>() : nullptr; b.binCap = binCap; b.tilesX = g.view.tilesX;
+		vkr_launch_bin_fill(c->stream, b, recCap);
+	}
+	// status for the overflow check at vkr_wait
+	PassStatus* st = &c->hStatus[statusSlot];
+	HIP_CHECK(hipMemcpyAsync(&st->recCount, counters, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_CHECK(hipMemcpyAsync(&st->binTotal, c->tileOffset.as<uint32_t>() + nTiles, 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_CHECK(hipGetLastError());
+	return VKR_OK;
+}
+
+static void fill_raster_args(vkr_context* c, const vkr_scene* s, const ViewDev& view, RasterArgs& r)
+{
+	r.sc = s->dev; r.view = view; r.clip = c->clip.as<float4>(); r.recs = c->recs.as<SubTri>();
+	r.tileOffset = c->tileOffset.as<uint32_t>(); r.binList = c->binList.as<uint32_t>(); r.binCap = c->binCap;
+	r.vis = nullptr; r.depthOut = nullptr; r.countOut = nullptr;
+}
+
+static int copy_out(vkr_context* c, void* dst, const void* src, size_t bytes)
+{
+	if (!dst || !bytes) return VKR_OK;
+	HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
+	return VKR_OK;
+}
+
+static void cam_mat(const float m[16], Mat4& M) { memcpy(M.m, m, sizeof(float) * 16); }
+
+// shadow pass (main/main.cpp:3950-3984) + regular pass (main/main.cpp:3987-4077)
+// over `view`; colour lands in `colourDst` (view-rectangle sized)
+static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_params& fp, const ViewDev& view, uint32_t* colourDst,
+                       uint32_t statusSlot, const vkr_frame_out* out, bool writeSide)
+{
+	const vkr_uniforms& u = fp.uniforms;
+	const uint32_t S = fp.shadow_size ? fp.shadow_size : 2048;
+	int rc;
+	if ((rc = c->shadow.ensure((size_t)S * S * 4))) return rc;
+	{
+		GeomPass g;
+		cam_mat(u.depthMVPUniform.depthMVP, g.M);
+		g.view = make_view(S, S, 0, 0, S, S);
+		g.first = 0; g.count = s->dev.nTriOpaque; // opaque meshes only
+		g.cullOpaque = 0; g.cullAlpha = 0; g.useOrderB = 0; g.alphaTest = 0; g.shadow = 1; g.keys = false;
+		if ((rc = run_geometry(c, s, g, statusSlot))) return rc;
+		StageTimer t(c, ST_RASTER_SHADOW);
+		RasterArgs r;
+		fill_raster_args(c, s, g.view, r);
+		r.depthOut = c->shadow.as<float>();
+		vkr_launch_raster(c->stream, RASTER_SHADOW, r);
+	}
+	const size_t n = (size_t)(view.x1 - view.x0) * (view.y1 - view.y0);
+	if ((rc = c->vis.ensure(n * 8))) return rc;
+	if ((rc = c->depth.ensure(n * 4))) return rc;
+	if ((rc = c->triId.ensure(n * 4))) return rc;
+	{
+		GeomPass g;
+		cam_mat(u.sceneUniforms.projCam, g.M);
+		g.view = view; g.first = 0; g.count = s->dev.nTri;
+		g.cullOpaque = 1; g.cullAlpha = 0; g.useOrderB = 0; g.alphaTest = 1; g.shadow = 0; g.keys = false;
+		if ((rc = run_geometry(c, s, g, statusSlot + 1))) return rc;
+		{
+			StageTimer t(c, ST_RASTER_VIS);
+			RasterArgs r;
+			fill_raster_args(c, s, view, r);
+			r.vis = c->vis.as<unsigned long long>();
+			vkr_launch_raster(c->stream, RASTER_VIS, r);
+		}
+		StageTimer t(c, ST_RESOLVE_FORWARD);
+		ResolveArgs a;
+		memset(&a, 0, sizeof a);
+		a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.vis = c->vis.as<unsigned long long>();
+		a.depth = c->depth.as<float>(); a.triId = c->triId.as<uint32_t>(); a.colour = colourDst;
+		a.shadow = c->shadow.as<float>(); a.shadowSize = S;
+		static const float biasMat[16] = { 0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 1.0f, 0, 0.5f, 0.5f, 0, 1.0f }; // default.vert:46-50
+		mat4_mul(biasMat, u.depthMVPUniform.depthMVP, a.lightMat.m);
+		memcpy(a.lightPos, u.lightUniforms.lightPos, 16); memcpy(a.lightColour, u.lightUniforms.lightColour, 16);
+		memcpy(a.camPos, u.sceneUniforms.camPos, 16);
+		vkr_launch_resolve_forward(c->stream, a);
+	}
+	if (writeSide) {
+		StageTimer t(c, ST_COPY_OUT);
+		if ((rc = copy_out(c, out->tri_id, c->triId.p, n * 4))) return rc;
+		if ((rc = copy_out(c, out->depth_bits, c->depth.p, n * 4))) return rc;
+		if ((rc = copy_out(c, out->shadow_map, c->shadow.p, (size_t)S * S * 4))) return rc;
+	}
+	return VKR_OK;
+}
+
+static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_params& fp, const vkr_frame_out& out, uint32_t statusSlot,
+                        uint32_t* nPasses)
+{
+	const vkr_uniforms& u = fp.uniforms;
+	uint32_t x0 = fp.rect_x0, y0 = fp.rect_y0, x1 = fp.rect_x1, y1 = fp.rect_y1;
+	if (x0 == 0 && y0 == 0 && x1 == 0 && y1 == 0) { x1 = fp.width; y1 = fp.height; }
+	if (fp.width == 0 || fp.height == 0 || fp.width > 16384 || fp.height > 16384)
+		return set_error(VKR_E_INVALID, "extent %ux%u out of range", fp.width, fp.height);
+	if (x0 >= x1 || y0 >= y1 || x1 > fp.width || y1 > fp.height)
+		return set_error(VKR_E_INVALID, "rectangle [%u,%u)x[%u,%u) outside the %ux%u frame", x0, x1, y0, y1, fp.width, fp.height);
+	const uint32_t S = fp.shadow_size ? fp.shadow_size : 2048;
+	if (S > 16384) return set_error(VKR_E_INVALID, "shadow_size %u out of range", S);
+	const ViewDev view = make_view(fp.width, fp.height, x0, y0, x1, y1);
+	const size_t n = (size_t)(x1 - x0) * (y1 - y0);
+	int rc;
+	if ((rc = c->colour.ensure(n * 4))) return rc;
+	const int dbg = fp.debugVisualisation;
+	*nPasses = 0;
+
+	if (fp.deferredShading && !fp.mosaicEffect) {
+		// ---- deferred: G-buffer subpass + lighting subpass (main/main.cpp:3836-3946)
+		if ((rc = c->vis.ensure(n * 8)) || (rc = c->depth.ensure(n * 4)) || (rc = c->triId.ensure(n * 4)) ||
+		    (rc = c->gN.ensure(n * 8)) || (rc = c->gA.ensure(n * 8))) return rc;
+		GeomPass g;
+		cam_mat(u.sceneUniforms.projCam, g.M);
+		g.view = view; g.first = 0; g.count = s->dev.nTri;
+		g.cullOpaque = 1; g.cullAlpha = 0; g.useOrderB = 0; g.alphaTest = 1; g.shadow = 0; g.keys = false;
+		if ((rc = run_geometry(c, s, g, statusSlot))) return rc;
+		*nPasses = 1;
+		{
+			StageTimer t(c, ST_RASTER_VIS);
+			RasterArgs r;
+			fill_raster_args(c, s, view, r);
+			r.vis = c->vis.as<unsigned long long>();
+			vkr_launch_raster(c->stream, RASTER_VIS, r);
+		}
+		{
+			StageTimer t(c, ST_RESOLVE_GBUF);
+			ResolveArgs a;
+			memset(&a, 0, sizeof a);
+			a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.vis = c->vis.as<unsigned long long>();
+			a.gN = c->gN.as<uint2>(); a.gA = c->gA.as<uint2>(); a.depth = c->depth.as<float>(); a.triId = c->triId.as<uint32_t>();
+			vkr_launch_resolve_gbuf(c->stream, a);
+		}
+		{
+			StageTimer t(c, ST_DEFERRED_LIGHT);
+			LightArgs l;
+			memset(&l, 0, sizeof l);
+			l.view = view; l.gN = c->gN.as<uint2>(); l.gA = c->gA.as<uint2>(); l.depth = c->depth.as<float>();
+			l.colour = c->colour.as<uint32_t>(); l.srgbThresh = c->dThresh;
+			float invCam[16], invProj[16];
+			mat4_inverse(u.sceneUniforms.camera, invCam);
+			mat4_inverse(u.sceneUniforms.projection, invProj);
+			mat4_mul(invCam, invProj, l.invPC.m); // deferredShading.frag:36
+			memcpy(l.camPos, u.sceneUniforms.camPos, 16);
+			for (int i = 0; i < VKR_NUM_LIGHTS; i++) {
+				memcpy(l.lightPos[i], u.multipleLightsUniform.light[i].lightPos, 16);
+				memcpy(l.lightCol[i], u.multipleLightsUniform.light[i].lightColour, 16);
+			}
+			// clear (0.1,0.1,0.1,0.1), main/main.cpp:3838-3841
+			const uint32_t c01 = host_srgb_encode(c->hThresh, 0.1f);
+			l.clearColour = c01 | (c01 << 8) | (c01 << 16) | ((uint32_t)floorf(0.1f * 255.0f + 0.5f) << 24);
+			vkr_launch_deferred_light(c->stream, l);
+		}
+		StageTimer t(c, ST_COPY_OUT);
+		if ((rc = copy_out(c, out.rgba8, c->colour.p, n * 4)) || (rc = copy_out(c, out.tri_id, c->triId.p, n * 4)) ||
+		    (rc = copy_out(c, out.depth_bits, c->depth.p, n * 4)) || (rc = copy_out(c, out.gbuf_normal, c->gN.p, n * 8)) ||
+		    (rc = copy_out(c, out.gbuf_albedo, c->gA.p, n * 8))) return rc;
+	} else if (!fp.mosaicEffect && dbg == 1) {
+		// ---- forward + shadow map (main/main.cpp:3948-4079)
+		if ((rc = run_forward(c, s, fp, view, c->colour.as<uint32_t>(), statusSlot, &out, true))) return rc;
+		*nPasses = 2;
+		StageTimer t(c, ST_COPY_OUT);
+		if ((rc = copy_out(c, out.rgba8, c->colour.p, n * 4))) return rc;
+	} else if (!fp.mosaicEffect && (dbg == 5 || dbg == 6)) {
+		// ---- overdraw / overshading counters (main/main.cpp:4081-4136): every mesh in file order, cull BACK
+		if ((rc = c->stencil.ensure(n)) || (rc = c->depth.ensure(n * 4))) return rc;
+		GeomPass g;
+		cam_mat(u.sceneUniforms.projCam, g.M);
+		g.view = view; g.first = 0; g.count = s->dev.nTri;
+		g.cullOpaque = 1; g.cullAlpha = 1; g.useOrderB = 1; g.alphaTest = 0; g.shadow = 0; g.keys = (dbg == 6);
+		if ((rc = run_geometry(c, s, g, statusSlot))) return rc;
+		*nPasses = 1;
+		if (dbg == 5) {
+			StageTimer t(c, ST_RASTER_COUNT);
+			RasterArgs r;
+			fill_raster_args(c, s, view, r);
+			r.countOut = c->stencil.as<uint8_t>();
+			vkr_launch_raster(c->stream, RASTER_COUNT, r);
+			// depth test disabled => no depth writes: the attachment keeps its clear value
+			vkr_launch_fill_u32(c->stream, c->depth.as<uint32_t>(), 0x3F800000u, n);
+		} else {
+			// submission order matters: sort every tile's bin by primitive.  The sort's
+			// segment offsets come from the device, so check them on the host first.
+			HIP_CHECK(hipStreamSynchronize(c->stream));
+			const PassStatus st = c->hStatus[statusSlot];
+			const uint32_t nTiles = view.tilesX * view.tilesY;
+			const uint32_t* vals = c->binList.as<uint32_t>();
+			if (!st.overflow && st.binTotal <= c->binCap && st.binTotal > 0) {
+				StageTimer t(c, ST_SORT_BINS);
+				if ((rc = c->binList2.ensure((size_t)c->binCap * 4)) || (rc = c->binKeys2.ensure((size_t)c->binCap * 4))) return rc;
+				const size_t tb = vkr_sort_bins_temp_bytes(st.binTotal, nTiles);
+				if ((rc = c->sortTemp.ensure(tb ? tb : 4))) return rc;
+				int which = vkr_sort_bins(c->stream, c->sortTemp.p, tb, c->binKeys.as<uint32_t>(), c->binKeys2.as<uint32_t>(),
+				                          c->binList.as<uint32_t>(), c->binList2.as<uint32_t>(), st.binTotal, nTiles,
+				                          c->tileOffset.as<uint32_t>());
+				if (which < 0) return set_error(VKR_E_DEVICE, "segmented sort of the tile bins failed");
+				vals = which ? c->binList2.as<uint32_t>() : c->binList.as<uint32_t>();
+			}
+			StageTimer t(c, ST_OVERSHADE);
+			OvershadeArgs o;
+			o.view = view; o.recs = c->recs.as<SubTri>(); o.tileOffset = c->tileOffset.as<uint32_t>(); o.binList = vals;
+			o.binCap = c->binCap; o.countOut = c->stencil.as<uint8_t>(); o.depthOut = c->depth.as<float>();
+			vkr_launch_overshade(c->stream, o);
+		}
+		{
+			StageTimer t(c, ST_OVERVIS_COLOUR);
+			vkr_launch_overvis_colour(c->stream, c->stencil.as<uint8_t>(), c->colour.as<uint32_t>(), c->dThresh, (uint32_t)n);
+		}
+		StageTimer t(c, ST_COPY_OUT);
+		if ((rc = copy_out(c, out.rgba8, c->colour.p, n * 4)) || (rc = copy_out(c, out.stencil, c->stencil.p, n)) ||
+		    (rc = copy_out(c, out.depth_bits, c->depth.p, n * 4))) return rc;
+	} else if (!fp.mosaicEffect) {
+		// ---- debug views 2/3/4 (main/main.cpp:4138-4193): every mesh in file order, cull BACK, no discard
+		if ((rc = c->vis.ensure(n * 8)) || (rc = c->depth.ensure(n * 4)) || (rc = c->triId.ensure(n * 4)) || (rc = c->mip.ensure(n))) return rc;
+		GeomPass g;
+		cam_mat(u.sceneUniforms.projCam, g.M);
+		g.view = view; g.first = 0; g.count = s->dev.nTri;
+		g.cullOpaque = 1; g.cullAlpha = 1; g.useOrderB = 1; g.alphaTest = 0; g.shadow = 0; g.keys = false;
+		if ((rc = run_geometry(c, s, g, statusSlot))) return rc;
+		*nPasses = 1;
+		{
+			StageTimer t(c, ST_RASTER_VIS);
+			RasterArgs r;
+			fill_raster_args(c, s, view, r);
+			r.vis = c->vis.as<unsigned long long>();
+			vkr_launch_raster(c->stream, RASTER_VIS, r);
+		}
+		{
+			StageTimer t(c, ST_RESOLVE_DEBUG);
+			ResolveArgs a;
+			memset(&a, 0, sizeof a);
+			a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.vis = c->vis.as<unsigned long long>();
+			a.depth = c->depth.as<float>(); a.triId = c->triId.as<uint32_t>(); a.mip = c->mip.as<uint8_t>();
+			a.colour = c->colour.as<uint32_t>(); a.debugMode = u.debugUniforms.debug; a.useOrderB = 1;
+			vkr_launch_resolve_debug(c->stream, a);
+		}
+		StageTimer t(c, ST_COPY_OUT);
+		if ((rc = copy_out(c, out.rgba8, c->colour.p, n * 4)) || (rc = copy_out(c, out.tri_id, c->triId.p, n * 4)) ||
+		    (rc = copy_out(c, out.depth_bits, c->depth.p, n * 4)) || (rc = copy_out(c, out.mip_level, c->mip.p, n))) return rc;
+	} else {
+		// ---- mosaic (main/main.cpp:4195-4320): forward pass into the offscreen sRGB image, then the
+		// 5x3 block post-process.  The reference records no shadow pass here and leaves the shadow
+		// descriptors unbound (undefined shadow term); the shadow map is rendered as in the regular path.
+		// A block of the rectangle can read up to 5 columns / 3 rows outside it.
+		const uint32_t hx0 = x0 >= 6 ? x0 - 6 : 0, hy0 = y0 >= 4 ? y0 - 4 : 0;
+		const uint32_t hx1 = std::min(fp.width, x1 + 1), hy1 = std::min(fp.height, y1 + 1);
+		const ViewDev hview = make_view(fp.width, fp.height, hx0, hy0, hx1, hy1);
+		const size_t hn = (size_t)(hx1 - hx0) * (hy1 - hy0);
+		if ((rc = c->colour2.ensure(hn * 4))) return rc;
+		const bool full = (hx0 == x0 && hy0 == y0 && hx1 == x1 && hy1 == y1);
+		if ((rc = run_forward(c, s, fp, hview, c->colour2.as<uint32_t>(), statusSlot, &out, full))) return rc;
+		*nPasses = 2;
+		{
+			StageTimer t(c, ST_MOSAIC);
+			vkr_launch_mosaic(c->stream, c->colour2.as<uint32_t>(), hx0, hy0, hx1 - hx0, hy1 - hy0, c->colour.as<uint32_t>(), view,
+			                  c->dDecode, c->dThresh);
+		}
+		StageTimer t(c, ST_COPY_OUT);
+		if ((rc = copy_out(c, out.rgba8, c->colour.p, n * 4))) return rc;
+	}
+	HIP_CHECK(hipGetLastError());
+	return VKR_OK;
+}
+
+extern "C" int vkr_render(vkr_context* c, const vkr_scene* s, const vkr_frame_params* fp, const vkr_frame_out* out)
+{
+	if (!c || !s || !fp || !out) return set_error(VKR_E_INVALID, "vkr_render: NULL argument");
+	if (s->ctx != c) return set_error(VKR_E_INVALID, "vkr_render: scene belongs to another context");
+	HIP_CHECK(hipSetDevice(c->device));
+	int rc;
+	if ((rc = ensure_status(c, 2))) return rc;
+	PendingFrame pf;
+	pf.scene = s; pf.params = *fp; pf.out = *out; pf.statusSlot = c->statusUsed; pf.nPasses = 0;
+	memset(&c->hStatus[pf.statusSlot], 0, sizeof(PassStatus) * 2);
+	if ((rc = submit_frame(c, s, pf.params, pf.out, pf.statusSlot, &pf.nPasses))) return rc;
+	c->statusUsed += 2;
+	c->pending.push_back(pf);
+	return VKR_OK;
+}
+
+extern "C" int vkr_wait(vkr_context* c)
+{
+	if (!c) return set_error(VKR_E_INVALID, "vkr_wait: NULL context");
+	HIP_CHECK(hipSetDevice(c->device));
+	HIP_CHECK(hipStreamSynchronize(c->stream));
+	// a pass that ran out of record or bin space produced an incomplete image:
+	// grow the scratch buffers and render those frames again
+	for (int attempt = 0; attempt < 6; attempt++) {
+		std::vector<PendingFrame> redo;
+		for (auto& pf : c->pending)
+			for (uint32_t k = 0; k < pf.nPasses; k++)
+				if (c->hStatus[pf.statusSlot + k].overflow) { redo.push_back(pf); break; }
+		c->pending.clear();
+		c->statusUsed = 0;
+		if (redo.empty()) return VKR_OK;
+		c->capScale *= 2.0;
+		for (auto& pf : redo) {
+			memset(&c->hStatus[c->statusUsed], 0, sizeof(PassStatus) * 2);
+			pf.statusSlot = c->statusUsed;
+			int rc = submit_frame(c, pf.scene, pf.params, pf.out, pf.statusSlot, &pf.nPasses);
+			if (rc) return rc;
+			c->statusUsed += 2;
+			c->pending.push_back(pf);
+		}
+		HIP_CHECK(hipStreamSynchronize(c->stream));
+	}
+	c->pending.clear();
+	c->statusUsed = 0;
+	return set_error(VKR_E_LIMIT, "tile bins still overflow after growing the scratch buffers");
+}

@@ -1,0 +1,354 @@
+// vkr_device.h — device-side data layout and the exact-arithmetic helpers the
+// kernels share.  Everything that feeds an integer output (coverage, depth
+// bits, mip level, alpha test) is written with explicit fma()/fmaf() and is
+// compiled with -ffp-contract=off, so the operation order below IS the
+// definition of the result.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VKR_TILE 32            // screen tile edge in pixels
+#define VKR_TILE_PIX (VKR_TILE * VKR_TILE)
+#define VKR_SUBPIX 256         // 8 sub-pixel bits
+#define VKR_GUARD 64.0         // guard band in NDC half-widths
+#define VKR_MAX_LEVELS 16
+#define VKR_MAX_SUBTRI 6       // a triangle clipped by near + 4 guard planes: <= 8 vertices
+#define VKR_NUM_LIGHTS_K 21     // deferredShading.frag:5
+#define VKR_NO_PRIM 0xffffffffu
+
+struct Mat4 { float m[16]; };  // column-major, glm::mat4
+
+// One texture: all mip levels in the scene's texel pool (RGBA8, one u32 per texel).
+struct TexInfo {
+	uint32_t offset[VKR_MAX_LEVELS]; // texel offset of each level in the pool
+	uint16_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS];
+	int32_t levels;
+	int32_t srgb;
+};
+
+// Material -> the five bindings of the material descriptor set
+// (main/main.cpp:770-846): 0 baseColor, 1 metalness, 2 roughness,
+// 3 alphaMask (baseColor when absent), 4 normalMap.
+struct MatInfo {
+	uint32_t tex[5];
+	uint32_t alphaTest; // 1 if the alpha texture holds any texel with alpha < 128
+	uint32_t _pad[2];
+};
+
+// Screen-space sub-triangle produced by triangle setup (64 bytes).
+struct SubTri {
+	int32_t X0, Y0, X1, Y1, X2, Y2; // snapped to 1/256 px, orientation positive
+	uint32_t prim;                  // submission-order primitive index
+	uint32_t flags;                 // bit0: alpha-tested, bit1: front-facing
+	double Az, Bz, Cz;              // z_ndc(sx,sy) = Az*sx + Bz*sy + Cz
+	double bias;                    // depth bias (shadow pass), 0 otherwise
+};
+#define VKR_ST_ALPHA 1u
+#define VKR_ST_FRONT 2u
+
+struct SceneDev {
+	const float* pos;        // 3 per vertex
+	const float* uv;         // 2 per vertex
+	const uint32_t* tcomp;   // packed TBN quaternion per vertex
+	const uint32_t* tri;     // 3 global vertex indices per triangle, submission order A
+	const uint32_t* triMat;  // material per triangle (order A)
+	const uint32_t* orderB;  // file-order rank of triangle t (order A index -> order B index)
+	const TexInfo* tex;
+	const MatInfo* mat;
+	const uint32_t* texels;  // texel pool
+	const float* srgbDecode; // 256
+	const float* srgbThresh; // 255
+	uint32_t nTri, nTriOpaque, nVert, nTex, nMat;
+};
+
+// Frame geometry shared by the raster / resolve kernels.
+struct ViewDev {
+	uint32_t W, H;           // full extent of the pass (viewport)
+	uint32_t x0, y0, x1, y1; // rectangle rendered by this context
+	uint32_t tilesX, tilesY;
+};
+
+// ---------------------------------------------------------------------------
+// bit helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// float -> half, round to nearest even
+__device__ __forceinline__ uint16_t vkr_f2h(float f)
+{
+	uint32_t x = f2u(f);
+	uint32_t sign = (x >> 16) & 0x8000u;
+	uint32_t ax = x & 0x7fffffffu;
+	if (ax >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? 0x200u : 0u));
+	if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+	if (ax < 0x33000001u) return (uint16_t)sign;
+	if (ax < 0x38800000u) {
+		uint32_t e = ax >> 23;
+		uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+		uint32_t shift = 126u - e;
+		uint32_t h = m >> shift;
+		uint32_t rem = m & ((1u << shift) - 1u);
+		uint32_t half = 1u << (shift - 1u);
+		if (rem > half || (rem == half && (h & 1u))) h++;
+		return (uint16_t)(sign | h);
+	}
+	uint32_t h = ((ax - 0x38000000u) >> 13);
+	uint32_t rem = ax & 0x1fffu;
+	if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+	return (uint16_t)(sign | h);
+}
+
+__device__ __forceinline__ float vkr_h2f(uint16_t h)
+{
+	uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+	uint32_t e = (h >> 10) & 0x1fu;
+	uint32_t m = h & 0x3ffu;
+	if (e == 0) {
+		if (m == 0) return u2f(sign);
+		float v = (float)m * 5.9604644775390625e-8f;
+		return sign ? -v : v;
+	}
+	if (e == 31) return u2f(sign | 0x7f800000u | (m << 13));
+	return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+__device__ __forceinline__ float vkr_clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+// linear [0,1] -> sRGB code: number of thresholds <= x
+__device__ __forceinline__ uint32_t vkr_srgb_encode(const float* thresh, float x)
+{
+	if (!(x > 0.0f)) return 0;
+	int lo = 0, hi = 255;
+#pragma unroll
+	for (int it = 0; it < 8; it++) {
+		int mid = (lo + hi) >> 1;
+		bool ge = (lo < hi) && (x >= thresh[mid]);
+		bool lt = (lo < hi) && !(x >= thresh[mid]);
+		if (ge) lo = mid + 1;
+		if (lt) hi = mid;
+	}
+	return (uint32_t)lo;
+}
+
+__device__ __forceinline__ uint32_t vkr_unorm_encode(float x)
+{
+	if (!(x > 0.0f)) return 0;
+	if (x >= 1.0f) return 255;
+	return (uint32_t)(int)floorf(x * 255.0f + 0.5f);
+}
+
+__device__ __forceinline__ uint32_t vkr_pack_colour(const float* thresh, float r, float g, float b, float a)
+{
+	return vkr_srgb_encode(thresh, vkr_clamp01(r)) | (vkr_srgb_encode(thresh, vkr_clamp01(g)) << 8) |
+	       (vkr_srgb_encode(thresh, vkr_clamp01(b)) << 16) | (vkr_unorm_encode(vkr_clamp01(a)) << 24);
+}
+
+__device__ __forceinline__ float vkr_lerp(float a, float b, float t) { return fmaf(t, b - a, a); }
+__device__ __forceinline__ float vkr_dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+	return fmaf(az, bz, fmaf(ay, by, ax * bx));
+}
+
+// gl_Position = M * vec4(p,1)
+__device__ __forceinline__ float4 vkr_xform(const Mat4& M, float x, float y, float z)
+{
+	float r[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		float t = M.m[0 * 4 + i] * x;
+		t = fmaf(M.m[1 * 4 + i], y, t);
+		t = fmaf(M.m[2 * 4 + i], z, t);
+		r[i] = t + M.m[3 * 4 + i];
+	}
+	return make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// ---------------------------------------------------------------------------
+// attribute planes of a triangle from its clip-space vertices (homogeneous
+// rasterisation): lambda_i(sx,sy) = a_i*sx + b_i*sy + c_i, sx,sy pixel coords.
+// ---------------------------------------------------------------------------
+struct TriPlanes {
+	double a[3], b[3], c[3];
+	double Az, Bz, Cz;
+};
+
+// returns false for a degenerate (zero-determinant) triangle
+__device__ __forceinline__ bool vkr_tri_planes(const float4 c0, const float4 c1, const float4 c2, uint32_t W, uint32_t H,
+                                               TriPlanes& pl)
+{
+	double hW = (double)W * 0.5, hH = (double)H * 0.5;
+	double hx0 = ((double)c0.x + (double)c0.w) * hW, hy0 = ((double)c0.y + (double)c0.w) * hH, hw0 = (double)c0.w;
+	double hx1 = ((double)c1.x + (double)c1.w) * hW, hy1 = ((double)c1.y + (double)c1.w) * hH, hw1 = (double)c1.w;
+	double hx2 = ((double)c2.x + (double)c2.w) * hW, hy2 = ((double)c2.y + (double)c2.w) * hH, hw2 = (double)c2.w;
+	// i=0: j=1,k=2
+	pl.a[0] = hy1 * hw2 - hy2 * hw1; pl.b[0] = hx2 * hw1 - hx1 * hw2; pl.c[0] = hx1 * hy2 - hx2 * hy1;
+	// i=1: j=2,k=0
+	pl.a[1] = hy2 * hw0 - hy0 * hw2; pl.b[1] = hx0 * hw2 - hx2 * hw0; pl.c[1] = hx2 * hy0 - hx0 * hy2;
+	// i=2: j=0,k=1
+	pl.a[2] = hy0 * hw1 - hy1 * hw0; pl.b[2] = hx1 * hw0 - hx0 * hw1; pl.c[2] = hx0 * hy1 - hx1 * hy0;
+	double det = (hx0 * pl.a[0] + hy0 * pl.b[0]) + hw0 * pl.c[0];
+	if (det == 0.0 || !(det == det)) return false;
+	double z0 = c0.z, z1 = c1.z, z2 = c2.z;
+	pl.Az = ((z0 * pl.a[0] + z1 * pl.a[1]) + z2 * pl.a[2]) / det;
+	pl.Bz = ((z0 * pl.b[0] + z1 * pl.b[1]) + z2 * pl.b[2]) / det;
+	pl.Cz = ((z0 * pl.c[0] + z1 * pl.c[1]) + z2 * pl.c[2]) / det;
+	return true;
+}
+
+__device__ __forceinline__ float vkr_depth_at(double Az, double Bz, double Cz, int px, int py)
+{
+	double sx = (double)px + 0.5, sy = (double)py + 0.5;
+	return (float)fma(Az, sx, fma(Bz, sy, Cz));
+}
+
+__device__ __forceinline__ void vkr_bary_at(const TriPlanes& pl, int px, int py, float b[3])
+{
+	double sx = (double)px + 0.5, sy = (double)py + 0.5;
+	double l0 = fma(pl.a[0], sx, fma(pl.b[0], sy, pl.c[0]));
+	double l1 = fma(pl.a[1], sx, fma(pl.b[1], sy, pl.c[1]));
+	double l2 = fma(pl.a[2], sx, fma(pl.b[2], sy, pl.c[2]));
+	double s = (l0 + l1) + l2;
+	b[0] = (float)(l0 / s); b[1] = (float)(l1 / s); b[2] = (float)(l2 / s);
+}
+
+__device__ __forceinline__ float vkr_interp(const float b[3], float f0, float f1, float f2)
+{
+	return fmaf(b[2], f2, fmaf(b[1], f1, b[0] * f0));
+}
+
+// uv at the pixel and fine derivatives inside its 2x2 quad: d = (du/dx, dv/dx, du/dy, dv/dy)
+__device__ __forceinline__ void vkr_uv_derivs(const TriPlanes& pl, int px, int py, const float b[3], float2 t0, float2 t1,
+                                              float2 t2, float uv[2], float d[4])
+{
+	float bx[3], by[3];
+	vkr_bary_at(pl, px ^ 1, py, bx);
+	vkr_bary_at(pl, px, py ^ 1, by);
+	uv[0] = vkr_interp(b, t0.x, t1.x, t2.x);
+	uv[1] = vkr_interp(b, t0.y, t1.y, t2.y);
+	float ux = vkr_interp(bx, t0.x, t1.x, t2.x), vx = vkr_interp(bx, t0.y, t1.y, t2.y);
+	float uy = vkr_interp(by, t0.x, t1.x, t2.x), vy = vkr_interp(by, t0.y, t1.y, t2.y);
+	if (px & 1) { d[0] = uv[0] - ux; d[1] = uv[1] - vx; } else { d[0] = ux - uv[0]; d[1] = vx - uv[1]; }
+	if (py & 1) { d[2] = uv[0] - uy; d[3] = uv[1] - vy; } else { d[2] = uy - uv[0]; d[3] = vy - uv[1]; }
+}
+
+// ---------------------------------------------------------------------------
+// texture sampling (sampler of utils/vkutil.cpp:179-196)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float vkr_log2_mantissa(float m)
+{
+	float t = m - 1.0f;
+	float s = t / (2.0f + t);
+	float s2 = s * s;
+	float p = 0.09090909090909091f;
+	p = fmaf(p, s2, 0.1111111111111111f);
+	p = fmaf(p, s2, 0.14285714285714285f);
+	p = fmaf(p, s2, 0.2f);
+	p = fmaf(p, s2, 0.3333333333333333f);
+	p = fmaf(p, s2, 1.0f);
+	float r = (s * p) * 2.8853900817779268f;
+	if (r > 1.0f) r = 1.0f;
+	return r;
+}
+
+__device__ __forceinline__ void vkr_lod_split(float rho2, int q, int& d, float& f)
+{
+	d = 0; f = 0.0f;
+	if (!(rho2 > 1.0f)) return;
+	uint32_t bits = f2u(rho2);
+	int e = (int)((bits >> 23) & 0xffu) - 127;
+	float m = u2f((bits & 0x7fffffu) | 0x3f800000u);
+	float p = vkr_log2_mantissa(m);
+	float fr = fmaf(p, 0.5f, (e & 1) ? 0.5f : 0.0f);
+	int lv = e >> 1;
+	if (lv >= q) { d = q; f = 0.0f; return; }
+	d = lv; f = fr;
+}
+
+__device__ __forceinline__ float vkr_rho2(const TexInfo& t, const float d[4])
+{
+	float tw = (float)t.w[0], th = (float)t.h[0];
+	float mx = d[0] * tw, my = d[1] * th;
+	float nx = d[2] * tw, ny = d[3] * th;
+	float rx = fmaf(my, my, mx * mx);
+	float ry = fmaf(ny, ny, nx * nx);
+	return (rx > ry) ? rx : ry;
+}
+
+__device__ __forceinline__ int vkr_wrap(int i, int n)
+{
+	int r = i % n;
+	return r < 0 ? r + n : r;
+}
+
+__device__ __forceinline__ void vkr_texel(const SceneDev& sc, const TexInfo& t, int level, int x, int y, float out[4])
+{
+	uint32_t p = sc.texels[t.offset[level] + (uint32_t)y * t.w[level] + (uint32_t)x];
+	if (t.srgb) {
+		out[0] = sc.srgbDecode[p & 0xffu];
+		out[1] = sc.srgbDecode[(p >> 8) & 0xffu];
+		out[2] = sc.srgbDecode[(p >> 16) & 0xffu];
+	} else {
+		out[0] = (float)(p & 0xffu) / 255.0f;
+		out[1] = (float)((p >> 8) & 0xffu) / 255.0f;
+		out[2] = (float)((p >> 16) & 0xffu) / 255.0f;
+	}
+	out[3] = (float)(p >> 24) / 255.0f;
+}
+
+__device__ __forceinline__ void vkr_bilinear(const SceneDev& sc, const TexInfo& t, int level, float u, float v, float out[4])
+{
+	int w = t.w[level], h = t.h[level];
+	float x = u * (float)w - 0.5f;
+	float y = v * (float)h - 0.5f;
+	if (!(fabsf(x) < 1.0e9f)) x = 0.0f;
+	if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
+	float x0f = floorf(x), y0f = floorf(y);
+	float fx = x - x0f, fy = y - y0f;
+	int x0 = vkr_wrap((int)x0f, w), x1 = vkr_wrap((int)x0f + 1, w);
+	int y0 = vkr_wrap((int)y0f, h), y1 = vkr_wrap((int)y0f + 1, h);
+	float t00[4], t10[4], t01[4], t11[4];
+	vkr_texel(sc, t, level, x0, y0, t00);
+	vkr_texel(sc, t, level, x1, y0, t10);
+	vkr_texel(sc, t, level, x0, y1, t01);
+	vkr_texel(sc, t, level, x1, y1, t11);
+#pragma unroll
+	for (int c = 0; c < 4; c++) out[c] = vkr_lerp(vkr_lerp(t00[c], t10[c], fx), vkr_lerp(t01[c], t11[c], fx), fy);
+}
+
+__device__ __forceinline__ void vkr_trilinear(const SceneDev& sc, const TexInfo& t, float u, float v, const float d[4],
+                                              float out[4])
+{
+	int lv; float fr;
+	vkr_lod_split(vkr_rho2(t, d), t.levels - 1, lv, fr);
+	if (fr == 0.0f) { vkr_bilinear(sc, t, lv, u, v, out); return; }
+	float a[4], b[4];
+	vkr_bilinear(sc, t, lv, u, v, a);
+	vkr_bilinear(sc, t, lv + 1, u, v, b);
+#pragma unroll
+	for (int c = 0; c < 4; c++) out[c] = vkr_lerp(a[c], b[c], fr);
+}
+
+// TBN decode (default.vert:57-81): GLSL mat3 column-major m[c*3+r]
+__device__ __forceinline__ void vkr_decode_tbn(uint32_t packed, float m[9])
+{
+	const float SQRT2 = 1.41421354f, INV_SQRT2 = 0.707106769f;
+	float r = (float)((packed >> 20) & 0x3ffu) / 1023.0f;
+	float g = (float)((packed >> 10) & 0x3ffu) / 1023.0f;
+	float b = (float)(packed & 0x3ffu) / 1023.0f;
+	int maxIndex = (int)(packed >> 30);
+	float s0 = r * SQRT2 - INV_SQRT2, s1 = g * SQRT2 - INV_SQRT2, s2 = b * SQRT2 - INV_SQRT2;
+	float dd = fmaf(s2, s2, fmaf(s1, s1, s0 * s0));
+	float maxc = sqrtf(1.0f - dd);
+	float qx, qy, qz, qw;
+	if (maxIndex == 0) { qx = maxc; qy = s0; qz = s1; qw = s2; }
+	else if (maxIndex == 1) { qx = s0; qy = maxc; qz = s1; qw = s2; }
+	else if (maxIndex == 2) { qx = s0; qy = s1; qz = maxc; qw = s2; }
+	else { qx = s0; qy = s1; qz = s2; qw = maxc; }
+	float qxx = qx * qx, qyy = qy * qy, qzz = qz * qz;
+	float qxz = qx * qz, qxy = qx * qy, qyz = qy * qz;
+	float qwx = qw * qx, qwy = qw * qy, qwz = qw * qz;
+	m[0] = 1.0f - 2.0f * (qyy + qzz); m[1] = 2.0f * (qxy + qwz);        m[2] = 2.0f * (qxz - qwy);
+	m[3] = 2.0f * (qxy - qwz);        m[4] = 1.0f - 2.0f * (qxx + qzz); m[5] = 2.0f * (qyz + qwx);
+	m[6] = 2.0f * (qxz + qwy);        m[7] = 2.0f * (qyz - qwx);        m[8] = 1.0f - 2.0f * (qxx + qyy);
+}

@@ -1,0 +1,107 @@
+// vkr_kernels.h — kernel argument blocks and host-side launch functions.
+#pragma once
+#include "vkr_device.h"
+
+struct SetupArgs {
+	SceneDev sc;
+	ViewDev view;
+	const float4* clip;
+	uint32_t first, count;     // triangle range, submission order A
+	int cullOpaque, cullAlpha; // 0 none, 1 back; alpha-masked meshes start at sc.nTriOpaque
+	int useOrderB;             // prim = file-order rank (passes that draw every mesh in file order)
+	int alphaTest;             // the pass's fragment shader discards on alpha < 0.5
+	int shadow;                // depth bias of the shadow pipeline
+	SubTri* recs;
+	uint2* recTiles;
+	uint32_t recCap;
+	uint32_t* recCount;
+	uint32_t* tileCount;
+	uint32_t* overflow;
+};
+
+struct BinFillArgs {
+	const SubTri* recs;
+	const uint2* recTiles;
+	const uint32_t* recCount;
+	uint32_t recCap;
+	const uint32_t* tileOffset;
+	uint32_t* cursor;
+	uint32_t* binList;
+	uint32_t* keys; // optional: prim per entry (ordered passes)
+	uint32_t binCap;
+	uint32_t tilesX;
+};
+
+enum { RASTER_VIS = 0, RASTER_SHADOW = 1, RASTER_COUNT = 2 };
+
+struct RasterArgs {
+	SceneDev sc;
+	ViewDev view;
+	const float4* clip;
+	const SubTri* recs;
+	const uint32_t* tileOffset;
+	const uint32_t* binList;
+	uint32_t binCap;
+	unsigned long long* vis; // RASTER_VIS: rect-sized visibility buffer
+	float* depthOut;         // RASTER_SHADOW: rect-sized depth
+	uint8_t* countOut;       // RASTER_COUNT: rect-sized saturating counter
+};
+
+struct OvershadeArgs {
+	ViewDev view;
+	const SubTri* recs;
+	const uint32_t* tileOffset;
+	const uint32_t* binList; // sorted by prim inside each tile
+	uint32_t binCap;
+	uint8_t* countOut;
+	float* depthOut;
+};
+
+struct ResolveArgs {
+	SceneDev sc;
+	ViewDev view;
+	const float4* clip;
+	const unsigned long long* vis;
+	// deferred
+	uint2* gN; uint2* gA;
+	// shared
+	float* depth; uint32_t* triId; uint8_t* mip; uint32_t* colour;
+	// forward
+	const float* shadow; uint32_t shadowSize; Mat4 lightMat;
+	float lightPos[4], lightColour[4], camPos[4];
+	int debugMode; int useOrderB;
+};
+
+struct LightArgs {
+	ViewDev view;
+	const uint2* gN; const uint2* gA; const float* depth;
+	uint32_t* colour;
+	const float* srgbThresh;
+	Mat4 invPC;          // inverse(camera) * inverse(projection)
+	float camPos[4];
+	float lightPos[VKR_NUM_LIGHTS_K][4];
+	float lightCol[VKR_NUM_LIGHTS_K][4];
+	uint32_t clearColour; // packed RGBA8 of the render pass clear value
+};
+
+void vkr_launch_xform(hipStream_t s, const float* pos, float4* clip, uint32_t nVert, const Mat4& M);
+void vkr_launch_setup(hipStream_t s, const SetupArgs& a);
+void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, uint32_t* offset, uint32_t* cursor, uint32_t nTiles,
+                           uint32_t cap, uint32_t* overflow);
+void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs);
+void vkr_launch_raster(hipStream_t s, int mode, const RasterArgs& a);
+void vkr_launch_overshade(hipStream_t s, const OvershadeArgs& a);
+void vkr_launch_resolve_gbuf(hipStream_t s, const ResolveArgs& a);
+void vkr_launch_resolve_forward(hipStream_t s, const ResolveArgs& a);
+void vkr_launch_resolve_debug(hipStream_t s, const ResolveArgs& a);
+void vkr_launch_deferred_light(hipStream_t s, const LightArgs& a);
+void vkr_launch_overvis_colour(hipStream_t s, const uint8_t* stencil, uint32_t* colour, const float* srgbThresh, uint32_t n);
+void vkr_launch_mosaic(hipStream_t s, const uint32_t* src, uint32_t srcX0, uint32_t srcY0, uint32_t srcW, uint32_t srcH,
+                       uint32_t* dst, ViewDev view, const float* srgbDecode, const float* srgbThresh);
+void vkr_launch_mip_level(hipStream_t s, uint32_t* texels, uint32_t srcOff, uint32_t sw, uint32_t sh, uint32_t dstOff,
+                          uint32_t dw, uint32_t dh, int srgb, const float* srgbDecode, const float* srgbThresh);
+void vkr_launch_fill_u32(hipStream_t s, uint32_t* dst, uint32_t value, size_t n);
+// segmented sort of bin entries by prim (ordered passes); temp storage managed by the caller
+size_t vkr_sort_bins_temp_bytes(uint32_t maxEntries, uint32_t nTiles);
+int vkr_sort_bins(hipStream_t s, void* temp, size_t tempBytes, uint32_t* keysIn, uint32_t* keysOut, uint32_t* valsIn,
+                  uint32_t* valsOut, uint32_t maxEntries, uint32_t nTiles, const uint32_t* tileOffset);

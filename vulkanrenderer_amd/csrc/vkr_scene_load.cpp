@@ -1,0 +1,251 @@
+// vkr_scene_load.cpp — reads a baked model file and the PNG textures it names,
+// then hands the arrays to vkr_scene_create.
+//
+// File format: load_baked_model_ (main/baked_model.cpp:70-174), variant
+// "21-tan".  Texture decode: what the reference gets from
+// stbi_load(path, ..., 4) with stbi_set_flip_vertically_on_load(1)
+// (utils/vkimage.cpp:62-65): 8-bit RGBA, grey replicated to RGB, missing alpha
+// = 255, 16-bit samples reduced to their high byte, rows bottom-up.
+#include "../../include/vkr_renderer.h"
+
+#include <zlib.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+int vkr_set_error_ext(int code, const char* fmt, ...); // vkr_api.cpp
+
+namespace {
+
+struct Reader {
+	const uint8_t* p; size_t n, off = 0;
+	bool take(void* dst, size_t k)
+	{
+		if (off + k > n) return false;
+		memcpy(dst, p + off, k);
+		off += k;
+		return true;
+	}
+	bool u32(uint32_t& v) { return take(&v, 4); } // little-endian host
+};
+
+bool read_file(const std::string& path, std::vector<uint8_t>& out)
+{
+	FILE* f = fopen(path.c_str(), "rb");
+	if (!f) return false;
+	fseek(f, 0, SEEK_END);
+	long sz = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	if (sz < 0) { fclose(f); return false; }
+	out.resize((size_t)sz);
+	size_t got = sz ? fread(out.data(), 1, (size_t)sz, f) : 0;
+	fclose(f);
+	return got == (size_t)sz;
+}
+
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+int paeth(int a, int b, int c)
+{
+	int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+	if (pa <= pb && pa <= pc) return a;
+	if (pb <= pc) return b;
+	return c;
+}
+
+// Non-interlaced PNG -> RGBA8, flipped vertically.  Returns an empty string on success.
+std::string decode_png(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgba, uint32_t& W, uint32_t& H)
+{
+	static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+	if (file.size() < 8 || memcmp(file.data(), sig, 8)) return "not a PNG file";
+	size_t off = 8;
+	uint32_t depth = 0, ctype = 0, interlace = 0;
+	bool haveHdr = false;
+	std::vector<uint8_t> idat, plte, trns;
+	while (off + 12 <= file.size()) {
+		uint32_t len = be32(&file[off]);
+		const uint8_t* type = &file[off + 4];
+		if (off + 12 + (size_t)len > file.size()) return "truncated chunk";
+		const uint8_t* data = &file[off + 8];
+		if (!memcmp(type, "IHDR", 4)) {
+			if (len < 13) return "bad IHDR";
+			W = be32(data); H = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12];
+			haveHdr = true;
+		} else if (!memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
+		else if (!memcmp(type, "tRNS", 4)) trns.assign(data, data + len);
+		else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+		else if (!memcmp(type, "IEND", 4)) break;
+		off += 12 + (size_t)len;
+	}
+	if (!haveHdr || W == 0 || H == 0) return "missing IHDR";
+	if (interlace) return "interlaced PNG is not supported";
+	int channels;
+	switch (ctype) {
+	case 0: channels = 1; break;
+	case 2: channels = 3; break;
+	case 3: channels = 1; break;
+	case 4: channels = 2; break;
+	case 6: channels = 4; break;
+	default: return "bad colour type";
+	}
+	if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) return "bad bit depth";
+	const size_t bpp = (size_t)channels * depth;           // bits per pixel
+	const size_t stride = ((size_t)W * bpp + 7) / 8;       // bytes per row
+	const size_t fbpp = (bpp + 7) / 8;                     // filter distance in bytes
+	std::vector<uint8_t> raw((stride + 1) * (size_t)H);
+	uLongf rawLen = (uLongf)raw.size();
+	if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size()) return "zlib inflate failed";
+	std::vector<uint8_t> img(stride * (size_t)H);
+	for (uint32_t y = 0; y < H; y++) {
+		const uint8_t ft = raw[(stride + 1) * y];
+		const uint8_t* src = &raw[(stride + 1) * y + 1];
+		uint8_t* cur = &img[stride * y];
+		const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+		for (size_t i = 0; i < stride; i++) {
+			int a = i >= fbpp ? cur[i - fbpp] : 0, b = up ? up[i] : 0, c = (up && i >= fbpp) ? up[i - fbpp] : 0;
+			int v = src[i];
+			switch (ft) {
+			case 0: break;
+			case 1: v += a; break;
+			case 2: v += b; break;
+			case 3: v += (a + b) >> 1; break;
+			case 4: v += paeth(a, b, c); break;
+			default: return "bad filter type";
+			}
+			cur[i] = (uint8_t)v;
+		}
+	}
+	rgba.resize((size_t)W * H * 4);
+	const uint32_t maxv = (1u << depth) - 1u;
+	for (uint32_t y = 0; y < H; y++) {
+		const uint8_t* row = &img[stride * y];
+		uint8_t* dst = &rgba[(size_t)(H - 1 - y) * W * 4]; // vertical flip
+		for (uint32_t x = 0; x < W; x++) {
+			uint32_t s[4] = { 0, 0, 0, 0 }; // raw samples
+			for (int ch = 0; ch < channels; ch++) {
+				const size_t bit = ((size_t)x * channels + ch) * depth;
+				if (depth == 8) s[ch] = row[bit >> 3];
+				else if (depth == 16) s[ch] = ((uint32_t)row[bit >> 3] << 8) | row[(bit >> 3) + 1];
+				else s[ch] = (row[bit >> 3] >> (8 - depth - (bit & 7))) & maxv;
+			}
+			uint8_t r, g, b, a = 255;
+			auto to8 = [&](uint32_t v) -> uint8_t {
+				if (depth == 16) return (uint8_t)(v >> 8);
+				if (depth == 8) return (uint8_t)v;
+				return (uint8_t)(v * (255u / maxv));
+			};
+			if (ctype == 3) {
+				const uint32_t idx = s[0];
+				if ((size_t)idx * 3 + 2 < plte.size()) { r = plte[idx * 3]; g = plte[idx * 3 + 1]; b = plte[idx * 3 + 2]; }
+				else { r = g = b = 0; }
+				if (idx < trns.size()) a = trns[idx];
+			} else if (ctype == 0 || ctype == 4) {
+				r = g = b = to8(s[0]);
+				if (ctype == 4) a = to8(s[1]);
+				else if (trns.size() >= 2 && s[0] == (((uint32_t)trns[0] << 8) | trns[1])) a = 0;
+			} else {
+				r = to8(s[0]); g = to8(s[1]); b = to8(s[2]);
+				if (ctype == 6) a = to8(s[3]);
+				else if (trns.size() >= 6 && s[0] == (((uint32_t)trns[0] << 8) | trns[1]) &&
+				         s[1] == (((uint32_t)trns[2] << 8) | trns[3]) && s[2] == (((uint32_t)trns[4] << 8) | trns[5])) a = 0;
+			}
+			dst[4 * x + 0] = r; dst[4 * x + 1] = g; dst[4 * x + 2] = b; dst[4 * x + 3] = a;
+		}
+	}
+	return "";
+}
+
+} // namespace
+
+extern "C" int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** out)
+{
+	if (!ctx || !path || !out) return vkr_set_error_ext(VKR_E_INVALID, "vkr_scene_load: NULL argument");
+	*out = nullptr;
+	std::vector<uint8_t> file;
+	if (!read_file(path, file)) return vkr_set_error_ext(VKR_E_IO, "load_baked_model(): unable to open '%s' for reading", path);
+	Reader rd{ file.data(), file.size() };
+	const char* slash = strrchr(path, '/');
+	const std::string prefix = slash ? std::string(path, slash + 1) : std::string();
+
+	static const char kMagic[16] = "\0\0COMP5892Mmesh"; // main/baked_model.cpp:12
+	static const char kVariant[16] = "21-tan";           // main/baked_model.cpp:13
+	char magic[16], variant[16];
+	if (!rd.take(magic, 16) || memcmp(magic, kMagic, 16)) return vkr_set_error_ext(VKR_E_IO, "%s: invalid file signature!", path);
+	if (!rd.take(variant, 16) || memcmp(variant, kVariant, 16)) {
+		variant[15] = 0;
+		return vkr_set_error_ext(VKR_E_IO, "%s: file variant is '%s', expected '%s'", path, variant, kVariant);
+	}
+	auto truncated = [&]() { return vkr_set_error_ext(VKR_E_IO, "%s: unexpected end of file at byte %zu", path, rd.off); };
+
+	uint32_t nTex = 0;
+	if (!rd.u32(nTex)) return truncated();
+	struct Tex { std::string path; uint8_t space, channels; std::vector<uint8_t> rgba; uint32_t w = 0, h = 0; };
+	std::vector<Tex> tex(nTex);
+	for (auto& t : tex) {
+		uint32_t len = 0;
+		if (!rd.u32(len)) return truncated();
+		if (len >= 32 * 1024) return vkr_set_error_ext(VKR_E_IO, "read_string_(): unexpectedly long string (%u bytes)", len); // kMaxString
+		std::string rel(len, '\0');
+		if (len && !rd.take(&rel[0], len)) return truncated();
+		// the writer stores the length including the terminating NUL; drop trailing NULs for the OS path
+		while (!rel.empty() && rel.back() == '\0') rel.pop_back();
+		t.path = prefix + rel;
+		if (!rd.take(&t.space, 1) || !rd.take(&t.channels, 1)) return truncated();
+	}
+	uint32_t nMat = 0;
+	if (!rd.u32(nMat)) return truncated();
+	std::vector<vkr_material_desc> mats(nMat);
+	for (auto& m : mats)
+		if (!rd.take(&m, sizeof m)) return truncated();
+	uint32_t nMesh = 0;
+	if (!rd.u32(nMesh)) return truncated();
+	struct Mesh { uint32_t mat, V, I; size_t pos, nrm, uv, tan, tc, idx; };
+	std::vector<Mesh> meshes(nMesh);
+	for (auto& m : meshes) {
+		if (!rd.u32(m.mat) || !rd.u32(m.V) || !rd.u32(m.I)) return truncated();
+		auto skip = [&](size_t bytes, size_t& at) { at = rd.off; if (rd.off + bytes > rd.n) return false; rd.off += bytes; return true; };
+		if (!skip((size_t)m.V * 12, m.pos) || !skip((size_t)m.V * 12, m.nrm) || !skip((size_t)m.V * 8, m.uv) ||
+		    !skip((size_t)m.V * 16, m.tan) || !skip((size_t)m.V * 4, m.tc) || !skip((size_t)m.I * 4, m.idx)) return truncated();
+	}
+	if (rd.off != rd.n) fprintf(stderr, "Note: '%s' contains trailing bytes\n", path); // main/baked_model.cpp:170-171
+
+	for (auto& t : tex) {
+		std::vector<uint8_t> png;
+		if (!read_file(t.path, png)) return vkr_set_error_ext(VKR_E_IO, "%s: Unable to load texture base image (cannot open)", t.path.c_str());
+		std::string err = decode_png(png, t.rgba, t.w, t.h);
+		if (!err.empty()) return vkr_set_error_ext(VKR_E_IO, "%s: Unable to load texture base image (%s)", t.path.c_str(), err.c_str());
+	}
+	// the arrays inside the file buffer may be unaligned: copy them out
+	std::vector<std::vector<uint8_t>> keep;
+	auto aligned = [&](size_t at, size_t bytes) -> const void* {
+		keep.emplace_back(file.begin() + (long)at, file.begin() + (long)(at + bytes));
+		return keep.back().data();
+	};
+	std::vector<vkr_texture_desc> td(nTex);
+	for (uint32_t i = 0; i < nTex; i++) {
+		memset(&td[i], 0, sizeof td[i]);
+		td[i].rgba8 = tex[i].rgba.data(); td[i].width = tex[i].w; td[i].height = tex[i].h;
+		td[i].space = tex[i].space; td[i].channels = tex[i].channels;
+	}
+	std::vector<vkr_mesh_desc> md(nMesh);
+	keep.reserve((size_t)nMesh * 6);
+	for (uint32_t i = 0; i < nMesh; i++) {
+		const Mesh& m = meshes[i];
+		memset(&md[i], 0, sizeof md[i]);
+		md[i].materialId = m.mat; md[i].vertexCount = m.V; md[i].indexCount = m.I;
+		md[i].positions = (const float*)aligned(m.pos, (size_t)m.V * 12);
+		md[i].normals = (const float*)aligned(m.nrm, (size_t)m.V * 12);
+		md[i].texcoords = (const float*)aligned(m.uv, (size_t)m.V * 8);
+		md[i].tangents = (const float*)aligned(m.tan, (size_t)m.V * 16);
+		md[i].tangentsComp = (const uint32_t*)aligned(m.tc, (size_t)m.V * 4);
+		md[i].indices = (const uint32_t*)aligned(m.idx, (size_t)m.I * 4);
+	}
+	vkr_scene_desc d;
+	memset(&d, 0, sizeof d);
+	d.textureCount = nTex; d.materialCount = nMat; d.meshCount = nMesh;
+	d.textures = td.data(); d.materials = mats.data(); d.meshes = md.data();
+	return vkr_scene_create(ctx, &d, out);
+}

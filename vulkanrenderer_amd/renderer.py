@@ -1,0 +1,180 @@
+"""Thin ctypes binding of libvkr_hip.so (include/vkr_renderer.h).
+
+There is no fallback path: if the HIP library is missing or fails to load the
+import of this module's users fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvkr_hip.so")
+_lib = None
+
+EXPORTS = [
+    "vkr_last_error", "vkr_context_create", "vkr_context_destroy", "vkr_scene_create", "vkr_scene_load",
+    "vkr_scene_destroy", "vkr_scene_stats", "vkr_scene_read_texture_level", "vkr_render", "vkr_wait",
+    "vkr_update_scene_uniforms", "vkr_update_depth_mvp_uniforms", "vkr_default_lights", "vkr_make_uniforms",
+    "vkr_profile_enable", "vkr_profile_reset", "vkr_stage_count", "vkr_stage_name", "vkr_profile_get",
+    "vkr_context_stream",
+]
+
+
+class VkrError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VkrError("HIP library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.vkr_last_error.restype = C.c_char_p
+        L.vkr_context_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.vkr_context_destroy.argtypes = [C.c_void_p]
+        L.vkr_context_destroy.restype = None
+        L.vkr_scene_create.argtypes = [C.c_void_p, C.POINTER(abi.SceneDesc), C.POINTER(C.c_void_p)]
+        L.vkr_scene_load.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.vkr_scene_destroy.argtypes = [C.c_void_p]
+        L.vkr_scene_destroy.restype = None
+        L.vkr_scene_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.vkr_scene_read_texture_level.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.vkr_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.FrameParams), C.POINTER(abi.FrameOut)]
+        L.vkr_wait.argtypes = [C.c_void_p]
+        L.vkr_update_scene_uniforms.argtypes = [C.POINTER(abi.SceneUniform), C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        L.vkr_update_scene_uniforms.restype = None
+        L.vkr_update_depth_mvp_uniforms.argtypes = [C.POINTER(abi.DepthMVP), C.POINTER(C.c_float)]
+        L.vkr_update_depth_mvp_uniforms.restype = None
+        L.vkr_default_lights.argtypes = [C.POINTER(abi.LightUniform), C.POINTER(abi.MultipleLights)]
+        L.vkr_default_lights.restype = None
+        L.vkr_make_uniforms.argtypes = [C.POINTER(abi.Uniforms), C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.c_int32]
+        L.vkr_make_uniforms.restype = None
+        L.vkr_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.vkr_profile_reset.argtypes = [C.c_void_p]
+        L.vkr_stage_name.restype = C.c_char_p
+        L.vkr_stage_name.argtypes = [C.c_int]
+        L.vkr_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.vkr_context_stream.restype = C.c_void_p
+        L.vkr_context_stream.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc:
+        raise VkrError("vkr error %d: %s" % (rc, lib().vkr_last_error().decode("utf-8", "replace")))
+
+
+def make_uniforms(width, height, camera2world_c16, debug=1):
+    """camera2world_c16: 16 floats, glm column-major (what UserState::camera2world holds)."""
+    u = abi.Uniforms()
+    lib().vkr_make_uniforms(C.byref(u), width, height, (C.c_float * 16)(*[float(v) for v in camera2world_c16]), debug)
+    return u
+
+
+SIDE = ("rgba8", "tri_id", "depth_bits", "mip_level", "stencil", "gbuf_normal", "gbuf_albedo", "shadow_map")
+
+
+class Context:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _check(lib().vkr_context_create(device, C.byref(self.h)))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().vkr_context_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def wait(self):
+        _check(lib().vkr_wait(self.h))
+
+    @property
+    def stream(self):
+        return lib().vkr_context_stream(self.h)
+
+    def profile(self, on=True):
+        _check(lib().vkr_profile_enable(self.h, int(on)))
+        _check(lib().vkr_profile_reset(self.h))
+
+    def profile_report(self):
+        """{stage: (total_ms, launches)} for stages that ran."""
+        out = {}
+        for s in range(lib().vkr_stage_count()):
+            ms, n = C.c_double(), C.c_uint64()
+            _check(lib().vkr_profile_get(self.h, s, C.byref(ms), C.byref(n)))
+            if n.value:
+                out[lib().vkr_stage_name(s).decode()] = (ms.value, n.value)
+        return out
+
+
+class Scene:
+    def __init__(self, ctx, packed=None, path=None):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        if packed is not None:
+            _check(lib().vkr_scene_create(ctx.h, C.byref(packed.desc), C.byref(self.h)))
+        else:
+            _check(lib().vkr_scene_load(ctx.h, path.encode(), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().vkr_scene_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stats(self):
+        t, v, b = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().vkr_scene_stats(self.h, C.byref(t), C.byref(v), C.byref(b)))
+        return dict(triangles=t.value, vertices=v.value, texture_bytes=b.value)
+
+    def texture_level(self, tex, level):
+        w, h = C.c_uint32(), C.c_uint32()
+        _check(lib().vkr_scene_read_texture_level(self.h, tex, level, None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value, 4), np.uint8)
+        _check(lib().vkr_scene_read_texture_level(self.h, tex, level, out.ctypes.data, C.byref(w), C.byref(h)))
+        return out
+
+    def submit(self, params, out):
+        """Asynchronous vkr_render with a caller-built FrameOut (host or device pointers)."""
+        _check(lib().vkr_render(self.ctx.h, self.h, C.byref(params), C.byref(out)))
+
+    def render(self, params, want=SIDE):
+        """Renders one frame into fresh numpy arrays and waits for it."""
+        W, H = params.width, params.height
+        x0, y0, x1, y1 = params.rect_x0, params.rect_y0, params.rect_x1, params.rect_y1
+        if (x0, y0, x1, y1) == (0, 0, 0, 0):
+            x1, y1 = W, H
+        rw, rh = x1 - x0, y1 - y0
+        S = params.shadow_size or 2048
+        bufs = {
+            "rgba8": np.zeros((rh, rw, 4), np.uint8), "tri_id": np.full((rh, rw), 0xFFFFFFFF, np.uint32),
+            "depth_bits": np.zeros((rh, rw), np.uint32), "mip_level": np.full((rh, rw), 0xFF, np.uint8),
+            "stencil": np.zeros((rh, rw), np.uint8), "gbuf_normal": np.zeros((rh, rw, 4), np.uint16),
+            "gbuf_albedo": np.zeros((rh, rw, 4), np.uint16),
+        }
+        if "shadow_map" in want:
+            bufs["shadow_map"] = np.zeros((S, S), np.float32)
+        out = abi.FrameOut()
+        for k, v in bufs.items():
+            if k in want:
+                setattr(out, k, v.ctypes.data)
+        self.submit(params, out)
+        self.ctx.wait()
+        return {k: v for k, v in bufs.items() if k in want}
