@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: deferred shading with all 21 brazier lights of the
+SunTemple-proxy scene, whole frames (transform, setup, binning, rasterise,
+G-buffer resolve, lighting), output left in device memory.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step is one frame for one camera pose.  With N > 1 (launched through
+torch.distributed.run, one rank per GPU) the camera poses of a fly-through are
+partitioned over the ranks (scene replicated per GPU, no data-path
+collective), so per-GPU work is fixed: weak scaling.  `--partition sortfirst`
+instead splits every frame into N horizontal bands and gathers them on rank 0
+over RCCL (strong scaling).
+
+Rank 0 prints one JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E peak
+LIGHT_BYTES_PER_PIXEL = 24   # 8 (normal+metal RGBA16F) + 8 (albedo+rough RGBA16F) + 4 (D32) read + 4 (RGBA8) written
+
+
+def fly_pose(i, n=512):
+    """Pose i of the fly-through: translate(0,-1,-90*i/(n-1)) * rotateY(0.35*sin(2*pi*i/128)), glm column-major."""
+    a = 0.35 * math.sin(2.0 * math.pi * i / 128.0)
+    c, s = math.cos(a), math.sin(a)
+    tz = -90.0 * i / (n - 1)
+    # columns: X=(c,0,-s), Y=(0,1,0), Z=(s,0,c), T=(0,-1,tz)
+    return [c, 0.0, -s, 0.0, 0.0, 1.0, 0.0, 0.0, s, 0.0, c, 0.0, 0.0, -1.0, tz, 1.0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--mode", default="deferred", choices=["deferred", "forward", "mosaic"])
+    ap.add_argument("--partition", default="poses", choices=["poses", "sortfirst"])
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--tex-size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="time every stage with HIP events (adds host overhead)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from vulkanrenderer_amd import abi, renderer, scenes
+
+    W, H = args.width, args.height
+    t0 = time.time()
+    packed = scenes.proxy_scene(detail=args.detail, tex_size=args.tex_size)
+    ctx = renderer.Context(local_rank)
+    scene = renderer.Scene(ctx, packed)
+    stats = scene.stats()
+    t_scene = time.time() - t0
+
+    kw = dict(deferred=(args.mode == "deferred"), mosaic=(args.mode == "mosaic"), debug=1)
+    if args.partition == "sortfirst" and world > 1:
+        band = (H + world - 1) // world
+        band += band & 1
+        y0, y1 = min(H, rank * band), min(H, (rank + 1) * band)
+        rect = (0, y0, W, y1)
+    else:
+        rect = None
+        y0, y1 = 0, H
+    rh = y1 - y0
+    out_t = torch.empty((max(rh, 1), W, 4), dtype=torch.uint8, device=dev)
+    gathered = None
+    if args.partition == "sortfirst" and world > 1 and rank == 0:
+        gathered = [torch.empty((min(H, (r + 1) * band) - min(H, r * band), W, 4), dtype=torch.uint8, device=dev) for r in range(world)]
+    fo = abi.FrameOut()
+    fo.rgba8 = out_t.data_ptr()
+
+    def frame(i):
+        pose_index = i if args.partition == "sortfirst" else (i * world + rank)
+        u = renderer.make_uniforms(W, H, fly_pose(pose_index % 512), 1)
+        p = abi.make_params(W, H, u, rect=rect, **kw)
+        scene.submit(p, fo)
+        if gathered is not None or (args.partition == "sortfirst" and world > 1):
+            ctx.wait()
+            dist.gather(out_t, gathered if rank == 0 else None, dst=0)
+
+    def barrier():
+        ctx.wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        frame(i)
+    barrier()
+    ctx.profile(True)
+    renderer._check(renderer.lib().vkr_profile_enable(ctx.h, 1 if args.profile_all else 2))
+    barrier()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        frame(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    report = ctx.profile_report()
+    renderer._check(renderer.lib().vkr_profile_enable(ctx.h, 0))
+
+    frames_total = args.steps * (1 if args.partition == "sortfirst" else world)
+    pixels_total = frames_total * W * H
+    value = pixels_total / elapsed / 1e6
+
+    roofline = None
+    light = report.get("k_deferred_light")
+    if light and light[1]:
+        avg_ms = light[0] / light[1]
+        launch_pixels = W * rh
+        achieved = LIGHT_BYTES_PER_PIXEL * launch_pixels / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "k_deferred_light",
+                    "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": LIGHT_BYTES_PER_PIXEL * launch_pixels}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        osc = oracle.OracleScene(packed)
+        u = oracle.make_uniforms(W, H, fly_pose(0), 1)
+        p = abi.make_params(W, H, u, **kw)
+        tc = time.perf_counter()
+        osc.render(p, want=("rgba8",))
+        dt = time.perf_counter() - tc
+        cpu = {"value": round(W * H / dt / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+               "sample": "1 frame of the same workload (pose 0, %dx%d %s) by the scalar CPU restatement oracle/vkr_oracle.c, %.1f s" % (W, H, args.mode, dt)}
+        osc.close()
+
+    if rank == 0:
+        line = {
+            "metric": "Mpix/s (frames/s) Sun Temple deferred 4K at 1/2/4/8 GPUs; % HBM roofline",
+            "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if args.partition == "sortfirst" else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "frames_per_s": round(frames_total / elapsed, 2),
+            "config": {"workload": "SunTemple-proxy v1 %s shading, 21 brazier lights, %dx%d, fly-through poses, whole frame" % (args.mode, W, H),
+                       "triangles": stats["triangles"], "vertices": stats["vertices"], "texture_bytes": stats["texture_bytes"],
+                       "partition": args.partition, "scene_setup_s": round(t_scene, 1)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if args.profile_all:
+            line["stages_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in report.items()}
+        print(json.dumps(line))
+    scene.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -212,7 +212,8 @@ VKR_API void vkr_make_uniforms(vkr_uniforms* u, uint32_t width, uint32_t height,
 
 /* Stage timing with HIP events on the context's stream.  Stage names are
  * returned by vkr_stage_name(); times are accumulated per stage since the
- * last vkr_profile_reset(). */
+ * last vkr_profile_reset().  on: 0 = off, 1 = every stage, 2 = only the
+ * deferred lighting kernel (two event records per frame). */
 VKR_API int vkr_profile_enable(vkr_context* ctx, int on);
 VKR_API int vkr_profile_reset(vkr_context* ctx);
 VKR_API int vkr_stage_count(void);

@@ -74,16 +74,18 @@ __device__ __forceinline__ void snap_vertex(double x, double y, double w, double
 	Y = (int32_t)(long long)floor(sy * (double)VKR_SUBPIX + 0.5);
 }
 
-// Finishes one fan triangle: facing, cull, orientation, bounding box, bias,
-// record emission and tile counting.
-__device__ __forceinline__ void emit_subtri(const SetupArgs& a, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2,
-                                            int32_t Y2, const TriPlanes& pl, uint32_t prim, uint32_t flags, int cull)
+// Finishes one fan triangle: facing, cull, orientation, bounding box, bias.
+// Returns false if nothing is to be drawn; otherwise fills the record and its
+// tile range.
+__device__ __forceinline__ bool prepare_subtri(const SetupArgs& a, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2,
+                                               int32_t Y2, const TriPlanes& pl, uint32_t prim, uint32_t flags, int cull,
+                                               SubTri& r, uint2& tiles)
 {
 	int64_t ax = (int64_t)X1 - X0, ay = (int64_t)Y1 - Y0, bx = (int64_t)X2 - X0, by = (int64_t)Y2 - Y0;
 	int64_t area2 = ax * by - bx * ay;
-	if (area2 == 0) return;
+	if (area2 == 0) return false;
 	bool front = area2 < 0; // Vulkan: a = -area2/2 > 0, frontFace = COUNTER_CLOCKWISE
-	if (cull == 1 && !front) return;
+	if (cull == 1 && !front) return false;
 	if (area2 < 0) { int32_t t = X1; X1 = X2; X2 = t; t = Y1; Y1 = Y2; Y2 = t; }
 	int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
 	int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
@@ -92,9 +94,8 @@ __device__ __forceinline__ void emit_subtri(const SetupArgs& a, int32_t X0, int3
 	int32_t py0 = (ymin - 128 + 255) >> 8, py1 = (ymax - 128) >> 8;
 	px0 = max(px0, (int32_t)a.view.x0); py0 = max(py0, (int32_t)a.view.y0);
 	px1 = min(px1, (int32_t)a.view.x1 - 1); py1 = min(py1, (int32_t)a.view.y1 - 1);
-	if (px0 > px1 || py0 > py1) return;
+	if (px0 > px1 || py0 > py1) return false;
 
-	SubTri r;
 	r.X0 = X0; r.Y0 = Y0; r.X1 = X1; r.Y1 = Y1; r.X2 = X2; r.Y2 = Y2;
 	r.prim = prim;
 	r.flags = flags | (front ? VKR_ST_FRONT : 0u);
@@ -114,14 +115,28 @@ __device__ __forceinline__ void emit_subtri(const SetupArgs& a, int32_t X0, int3
 		double rr = __longlong_as_double((long long)(e - 23 + 1023) << 52);
 		r.bias = m * 10.0 + rr * 7.0;
 	}
-	uint32_t slot = atomicAdd(a.recCount, 1u);
-	if (slot >= a.recCap) { atomicOr(a.overflow, 1u); return; }
-	a.recs[slot] = r;
 	uint32_t tx0 = (uint32_t)(px0 - (int32_t)a.view.x0) / VKR_TILE, tx1 = (uint32_t)(px1 - (int32_t)a.view.x0) / VKR_TILE;
 	uint32_t ty0 = (uint32_t)(py0 - (int32_t)a.view.y0) / VKR_TILE, ty1 = (uint32_t)(py1 - (int32_t)a.view.y0) / VKR_TILE;
-	a.recTiles[slot] = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+	tiles = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+	return true;
+}
+
+__device__ __forceinline__ void commit_subtri(const SetupArgs& a, uint32_t slot, const SubTri& r, uint2 tiles)
+{
+	if (slot >= a.recCap) { atomicOr(a.overflow, 1u); return; }
+	a.recs[slot] = r;
+	a.recTiles[slot] = tiles;
+	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
 	for (uint32_t ty = ty0; ty <= ty1; ty++)
 		for (uint32_t tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tileCount[ty * a.view.tilesX + tx], 1u);
+}
+
+__device__ __forceinline__ void emit_subtri(const SetupArgs& a, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2,
+                                            int32_t Y2, const TriPlanes& pl, uint32_t prim, uint32_t flags, int cull)
+{
+	SubTri r; uint2 tiles;
+	if (!prepare_subtri(a, X0, Y0, X1, Y1, X2, Y2, pl, prim, flags, cull, r, tiles)) return;
+	commit_subtri(a, atomicAdd(a.recCount, 1u), r, tiles);
 }
 
 __device__ __noinline__ void setup_clipped(const SetupArgs& a, float4 c0, float4 c1, float4 c2, const TriPlanes& pl,
@@ -139,57 +154,73 @@ __device__ __noinline__ void setup_clipped(const SetupArgs& a, float4 c0, float4
 	for (int i = 1; i + 1 < n; i++) emit_subtri(a, X[0], Y[0], X[i], Y[i], X[i + 1], Y[i + 1], pl, prim, flags, cull);
 }
 
+// One thread per triangle.  Unclipped triangles (the common case) allocate
+// their record slots with one atomic per wavefront; clipped ones take the
+// slow path.
 __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 {
-	uint32_t t = a.first + blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= a.first + a.count) return;
-	uint32_t i0 = a.sc.tri[3 * (size_t)t + 0], i1 = a.sc.tri[3 * (size_t)t + 1], i2 = a.sc.tri[3 * (size_t)t + 2];
-	float4 c0 = a.clip[i0], c1 = a.clip[i1], c2 = a.clip[i2];
-	// NaN anywhere -> drop
-	if (!(c0.x == c0.x) || !(c0.y == c0.y) || !(c0.z == c0.z) || !(c0.w == c0.w)) return;
-	if (!(c1.x == c1.x) || !(c1.y == c1.y) || !(c1.z == c1.z) || !(c1.w == c1.w)) return;
-	if (!(c2.x == c2.x) || !(c2.y == c2.y) || !(c2.z == c2.z) || !(c2.w == c2.w)) return;
-	// trivial reject against -w<=x,y<=w, 0<=z<=w
-	if ((c0.x < -c0.w) & (c1.x < -c1.w) & (c2.x < -c2.w)) return;
-	if ((c0.x > c0.w) & (c1.x > c1.w) & (c2.x > c2.w)) return;
-	if ((c0.y < -c0.w) & (c1.y < -c1.w) & (c2.y < -c2.w)) return;
-	if ((c0.y > c0.w) & (c1.y > c1.w) & (c2.y > c2.w)) return;
-	if ((c0.z < 0.0f) & (c1.z < 0.0f) & (c2.z < 0.0f)) return;
-	if ((c0.z > c0.w) & (c1.z > c1.w) & (c2.z > c2.w)) return;
-
-	TriPlanes pl;
-	if (!vkr_tri_planes(c0, c1, c2, a.view.W, a.view.H, pl)) return;
-
-	bool isAlphaMesh = t >= a.sc.nTriOpaque;
-	int cull = isAlphaMesh ? a.cullAlpha : a.cullOpaque;
-	uint32_t prim = a.useOrderB ? a.sc.orderB[t] : t;
-	uint32_t flags = 0;
-	if (a.alphaTest && a.sc.mat[a.sc.triMat[t]].alphaTest) flags |= VKR_ST_ALPHA;
-
-	double hW = (double)a.view.W * 0.5, hH = (double)a.view.H * 0.5;
-	// does any vertex violate the near or a guard-band plane?
-	bool needClip = false;
-	{
-		const float4 c[3] = { c0, c1, c2 };
+	const uint32_t t = a.first + blockIdx.x * blockDim.x + threadIdx.x;
+	bool emit = false;
+	SubTri rec; uint2 tiles = make_uint2(0, 0);
+	if (t < a.first + a.count) {
+		const uint32_t i0 = a.sc.tri[3 * (size_t)t + 0], i1 = a.sc.tri[3 * (size_t)t + 1], i2 = a.sc.tri[3 * (size_t)t + 2];
+		const float4 c0 = a.clip[i0], c1 = a.clip[i1], c2 = a.clip[i2];
+		bool ok = true;
+		// NaN anywhere -> drop
+		if (!(c0.x == c0.x) || !(c0.y == c0.y) || !(c0.z == c0.z) || !(c0.w == c0.w)) ok = false;
+		if (!(c1.x == c1.x) || !(c1.y == c1.y) || !(c1.z == c1.z) || !(c1.w == c1.w)) ok = false;
+		if (!(c2.x == c2.x) || !(c2.y == c2.y) || !(c2.z == c2.z) || !(c2.w == c2.w)) ok = false;
+		// trivial reject against -w<=x,y<=w, 0<=z<=w
+		if ((c0.x < -c0.w) & (c1.x < -c1.w) & (c2.x < -c2.w)) ok = false;
+		if ((c0.x > c0.w) & (c1.x > c1.w) & (c2.x > c2.w)) ok = false;
+		if ((c0.y < -c0.w) & (c1.y < -c1.w) & (c2.y < -c2.w)) ok = false;
+		if ((c0.y > c0.w) & (c1.y > c1.w) & (c2.y > c2.w)) ok = false;
+		if ((c0.z < 0.0f) & (c1.z < 0.0f) & (c2.z < 0.0f)) ok = false;
+		if ((c0.z > c0.w) & (c1.z > c1.w) & (c2.z > c2.w)) ok = false;
+		TriPlanes pl;
+		if (ok && !vkr_tri_planes(c0, c1, c2, a.view.W, a.view.H, pl)) ok = false;
+		if (ok) {
+			const bool isAlphaMesh = t >= a.sc.nTriOpaque;
+			const int cull = isAlphaMesh ? a.cullAlpha : a.cullOpaque;
+			const uint32_t prim = a.useOrderB ? a.sc.orderB[t] : t;
+			uint32_t flags = 0;
+			if (a.alphaTest && a.sc.mat[a.sc.triMat[t]].alphaTest) flags |= VKR_ST_ALPHA;
+			const double hW = (double)a.view.W * 0.5, hH = (double)a.view.H * 0.5;
+			// does any vertex violate the near or a guard-band plane?
+			bool needClip = false;
+			{
+				const float4 c[3] = { c0, c1, c2 };
 #pragma unroll
-		for (int i = 0; i < 3; i++) {
-			double x = c[i].x, y = c[i].y, z = c[i].z, w = c[i].w;
-			if (!(z >= 0.0)) needClip = true;
-			if (!(x + VKR_GUARD * w >= 0.0)) needClip = true;
-			if (!(VKR_GUARD * w - x >= 0.0)) needClip = true;
-			if (!(y + VKR_GUARD * w >= 0.0)) needClip = true;
-			if (!(VKR_GUARD * w - y >= 0.0)) needClip = true;
+				for (int i = 0; i < 3; i++) {
+					double x = c[i].x, y = c[i].y, z = c[i].z, w = c[i].w;
+					if (!(z >= 0.0)) needClip = true;
+					if (!(x + VKR_GUARD * w >= 0.0)) needClip = true;
+					if (!(VKR_GUARD * w - x >= 0.0)) needClip = true;
+					if (!(y + VKR_GUARD * w >= 0.0)) needClip = true;
+					if (!(VKR_GUARD * w - y >= 0.0)) needClip = true;
+				}
+			}
+			if (needClip) {
+				setup_clipped(a, c0, c1, c2, pl, prim, flags, cull, hW, hH);
+			} else {
+				int32_t X0, Y0, X1, Y1, X2, Y2;
+				snap_vertex(c0.x, c0.y, c0.w, hW, hH, X0, Y0);
+				snap_vertex(c1.x, c1.y, c1.w, hW, hH, X1, Y1);
+				snap_vertex(c2.x, c2.y, c2.w, hW, hH, X2, Y2);
+				emit = prepare_subtri(a, X0, Y0, X1, Y1, X2, Y2, pl, prim, flags, cull, rec, tiles);
+			}
 		}
 	}
-	if (needClip) {
-		setup_clipped(a, c0, c1, c2, pl, prim, flags, cull, hW, hH);
-		return;
+	// wave-aggregated slot allocation
+	const unsigned long long mask = __ballot(emit);
+	if (mask) {
+		const uint32_t lane = threadIdx.x & 63;
+		const int leader = __ffsll((long long)mask) - 1;
+		uint32_t base = 0;
+		if ((int)lane == leader) base = atomicAdd(a.recCount, (uint32_t)__popcll(mask));
+		base = __shfl(base, leader, 64);
+		if (emit) commit_subtri(a, base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), rec, tiles);
 	}
-	int32_t X0, Y0, X1, Y1, X2, Y2;
-	snap_vertex(c0.x, c0.y, c0.w, hW, hH, X0, Y0);
-	snap_vertex(c1.x, c1.y, c1.w, hW, hH, X1, Y1);
-	snap_vertex(c2.x, c2.y, c2.w, hW, hH, X2, Y2);
-	emit_subtri(a, X0, Y0, X1, Y1, X2, Y2, pl, prim, flags, cull);
 }
 
 // ---------------------------------------------------------------------------

@@ -98,6 +98,8 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 		else if (MODE == RASTER_SHADOW) tb32[i] = 0x3F800000u;
 		else tb32[i] = 0u;
 	}
+	__shared__ int sAnyAlpha;
+	if (tid == 0) sAnyAlpha = 0;
 	__syncthreads();
 
 	uint32_t beg = a.tileOffset[tile], end = a.tileOffset[tile + 1];
@@ -105,16 +107,34 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 	if (beg > end) beg = end;
 	const uint32_t n = end - beg;
 
+	// Visibility passes run twice over the bin: first every sub-triangle that
+	// needs no alpha test, then the alpha-tested ones, whose (expensive)
+	// texture lookup is skipped for fragments already behind the tile's depth.
+	const int nPass = (MODE == RASTER_VIS) ? 2 : 1;
+	for (int pass = 0; pass < nPass; pass++) {
+	if (pass == 1) {
+		__syncthreads();
+		if (!sAnyAlpha) break;
+	}
 	for (uint32_t base = 0; base < n; base += 256) {
 		const uint32_t i = base + tid;
-		const bool has = i < n;
+		bool has = i < n;
 		SubTri s;
 		int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
 		if (has) {
-			s = a.recs[a.binList[beg + i]];
-			tri_bbox(s, bx0, by0, bx1, by1);
-			bx0 = max(bx0, ox); by0 = max(by0, oy); bx1 = min(bx1, ex); by1 = min(by1, ey);
-		} else {
+			const uint32_t ri = a.binList[beg + i];
+			if (MODE == RASTER_VIS) {
+				const bool isAlpha = (a.recs[ri].flags & VKR_ST_ALPHA) != 0;
+				if (pass == 0 && isAlpha) sAnyAlpha = 1;
+				if (isAlpha != (pass == 1)) has = false;
+			}
+			if (has) {
+				s = a.recs[ri];
+				tri_bbox(s, bx0, by0, bx1, by1);
+				bx0 = max(bx0, ox); by0 = max(by0, oy); bx1 = min(bx1, ex); by1 = min(by1, ey);
+			}
+		}
+		if (!has) {
 			s.X0 = s.Y0 = s.X1 = s.Y1 = s.X2 = s.Y2 = 0; s.prim = 0; s.flags = 0; s.Az = s.Bz = s.Cz = s.bias = 0.0;
 		}
 		const bool nonEmpty = has && bx0 <= bx1 && by0 <= by1;
@@ -172,13 +192,19 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 					EdgeSetup E;
 					edge_setup(w, px, py, E);
 					if ((E.e0 | E.e1 | E.e2) < 0) continue;
+					const int li = (py - oy) * VKR_TILE + (px - ox);
 					if (walpha) {
 						if (!plOk) continue;
+						// a fragment behind the depth already in the tile cannot win the atomicMin
+						const float z = vkr_depth_at(w.Az, w.Bz, w.Cz, px, py);
+						if (!(z >= 0.0f && z <= 1.0f)) continue;
+						if (f2u(z) > (uint32_t)(tb64[li] >> 32)) continue;
 						if (!alpha_pass(a, pl, t0, t1, t2, a.sc.tex[alphaTex], px, py)) continue;
 					}
-					fragment<MODE>(tb64, tb32, (py - oy) * VKR_TILE + (px - ox), w, px, py);
+					fragment<MODE>(tb64, tb32, li, w, px, py);
 				}
 		}
+	}
 	}
 	__syncthreads();
 

@@ -106,7 +106,7 @@ struct vkr_context {
 	uint32_t statusCap = 0, statusUsed = 0;
 	std::vector<PendingFrame> pending;
 	// profiling
-	bool profiling = false;
+	int profiling = 0; // 0 off, 1 every stage, 2 the lighting stage only
 	std::vector<Timed> timed;
 	std::vector<hipEvent_t> eventPool;
 	double stageMs[ST_COUNT] = { 0 };
@@ -344,7 +344,7 @@ static hipEvent_t get_event(vkr_context* c)
 
 struct StageTimer {
 	vkr_context* c; Timed t; bool on;
-	StageTimer(vkr_context* ctx, int stage) : c(ctx), on(ctx->profiling)
+	StageTimer(vkr_context* ctx, int stage) : c(ctx), on(ctx->profiling == 1 || (ctx->profiling == 2 && stage == ST_DEFERRED_LIGHT))
 	{
 		if (!on) return;
 		t.stage = stage; t.a = get_event(c); t.b = get_event(c);
@@ -371,7 +371,7 @@ static void drain_timers(vkr_context* c)
 extern "C" int vkr_profile_enable(vkr_context* c, int on)
 {
 	if (!c) return set_error(VKR_E_INVALID, "NULL context");
-	c->profiling = on != 0;
+	c->profiling = on;
 	return VKR_OK;
 }
 extern "C" int vkr_profile_reset(vkr_context* c)

@@ -232,7 +232,7 @@ def micro_scene(tex_size=16, seed=7):
     return PackedScene(textures, materials, meshes)
 
 
-def proxy_scene(detail=1.0, tex_size=1024, seed=PROXY_SEED, materials_total=48):
+def proxy_scene(detail=1.0, tex_size=1024, seed=PROXY_SEED, materials_total=48, foliage=True):
     """SunTemple-proxy v1.  detail=1.0 gives about 5.2e5 triangles; smaller
     values thin the tessellation for tests."""
     rng = np.random.default_rng(seed)
@@ -290,6 +290,6 @@ def proxy_scene(detail=1.0, tex_size=1024, seed=PROXY_SEED, materials_total=48):
                                     opaque[k % len(opaque)], flutes=6, depth=0.15)); k += 1
     # foliage: three clusters of alpha-masked quads
     fcount = max(4, int(round(500 * detail)))
-    for i, c in enumerate(((-6.0, -3.5, -8.0), (6.5, -3.5, -30.0), (-5.0, -3.5, -55.0))):
+    for i, c in enumerate(((-6.0, -3.5, -8.0), (6.5, -3.5, -30.0), (-5.0, -3.5, -55.0)) if foliage else ()):
         meshes += foliage_cluster(rng, c, fcount, 1.4, alpha[i % len(alpha)])
     return PackedScene(textures, materials, meshes)
