@@ -643,7 +643,9 @@ ORA_API uint32_t ora_pack_tbn(const float Tin[3], const float Nin[3])
 /* geometry: transform, clip, snap, planes                                   */
 /* ------------------------------------------------------------------------ */
 
-#define GUARD 64.0 /* guard band, in NDC half-widths */
+/* guard band in NDC half-widths: small enough that the snapped coordinates keep
+ * every edge function below 2^53 (exact in double as well as in int64) */
+static double guard_band(uint32_t W, uint32_t H) { return ((W > H ? W : H) <= 4096u) ? 32.0 : 8.0; }
 #define SUBPIX 256
 
 /* gl_Position = M * vec4(p, 1) */
@@ -669,7 +671,7 @@ typedef struct {
 
 typedef struct { double x, y, z, w; } ClipV;
 
-static int clip_poly(ClipV* v, int n, int plane)
+static int clip_poly(ClipV* v, int n, int plane, double GUARD)
 {
 	/* plane: 0 z>=0, 1 x>=-Gw, 2 x<=Gw, 3 y>=-Gw, 4 y<=Gw */
 	double d[10];
@@ -739,19 +741,22 @@ static int tri_setup(const float* c0, const float* c1, const float* c2, uint32_t
 	double det = (hx[0] * pl->a[0] + hy[0] * pl->b[0]) + hw[0] * pl->c[0];
 	if (det == 0.0 || !(det == det)) return 0;
 	double z0 = c[0][2], z1 = c[1][2], z2 = c[2][2];
-	pl->Az = ((z0 * pl->a[0] + z1 * pl->a[1]) + z2 * pl->a[2]) / det;
-	pl->Bz = ((z0 * pl->b[0] + z1 * pl->b[1]) + z2 * pl->b[2]) / det;
-	pl->Cz = ((z0 * pl->c[0] + z1 * pl->c[1]) + z2 * pl->c[2]) / det;
+	double idet = 1.0 / det;
+	pl->Az = ((z0 * pl->a[0] + z1 * pl->a[1]) + z2 * pl->a[2]) * idet;
+	pl->Bz = ((z0 * pl->b[0] + z1 * pl->b[1]) + z2 * pl->b[2]) * idet;
+	pl->Cz = ((z0 * pl->c[0] + z1 * pl->c[1]) + z2 * pl->c[2]) * idet;
 
 	ClipV v[10];
 	int n = 3;
 	for (int i = 0; i < 3; i++) { v[i].x = c[i][0]; v[i].y = c[i][1]; v[i].z = c[i][2]; v[i].w = c[i][3]; }
-	for (int p = 0; p < 5 && n >= 3; p++) n = clip_poly(v, n, p);
+	const double G = guard_band(W, H);
+	for (int p = 0; p < 5 && n >= 3; p++) n = clip_poly(v, n, p, G);
 	if (n < 3) return 0;
 	int64_t X[10], Y[10];
 	for (int i = 0; i < n; i++) {
-		double sx = (v[i].x / v[i].w + 1.0) * hW;
-		double sy = (v[i].y / v[i].w + 1.0) * hH;
+		double iw = 1.0 / v[i].w;
+		double sx = (v[i].x * iw + 1.0) * hW;
+		double sy = (v[i].y * iw + 1.0) * hH;
 		X[i] = (int64_t)floor(sx * (double)SUBPIX + 0.5);
 		Y[i] = (int64_t)floor(sy * (double)SUBPIX + 0.5);
 	}
@@ -783,8 +788,8 @@ static inline void bary_at(const TriPlanes* pl, int px, int py, float b[3])
 	double l0 = fma(pl->a[0], sx, fma(pl->b[0], sy, pl->c[0]));
 	double l1 = fma(pl->a[1], sx, fma(pl->b[1], sy, pl->c[1]));
 	double l2 = fma(pl->a[2], sx, fma(pl->b[2], sy, pl->c[2]));
-	double s = (l0 + l1) + l2;
-	b[0] = (float)(l0 / s); b[1] = (float)(l1 / s); b[2] = (float)(l2 / s);
+	double is = 1.0 / ((l0 + l1) + l2);
+	b[0] = (float)(l0 * is); b[1] = (float)(l1 * is); b[2] = (float)(l2 * is);
 }
 
 static inline float interp(const float b[3], float f0, float f1, float f2)

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_xform(const float* __restrict__ pos, fl
 // ---------------------------------------------------------------------------
 struct ClipV { double x, y, z, w; };
 
-__device__ __forceinline__ double plane_dist(const ClipV& v, int plane)
+__device__ __forceinline__ double plane_dist(const ClipV& v, int plane, double VKR_GUARD)
 {
 	switch (plane) {
 	case 0: return v.z;
@@ -34,12 +34,12 @@ __device__ __forceinline__ double plane_dist(const ClipV& v, int plane)
 
 // Sutherland-Hodgman against one plane; new vertices are always interpolated
 // from the inside vertex towards the outside one.
-__device__ __noinline__ int clip_poly(ClipV* v, int n, int plane)
+__device__ __noinline__ int clip_poly(ClipV* v, int n, int plane, double guard)
 {
 	double d[10];
 	bool anyOut = false;
 	for (int i = 0; i < n; i++) {
-		d[i] = plane_dist(v[i], plane);
+		d[i] = plane_dist(v[i], plane, guard);
 		if (!(d[i] >= 0.0)) anyOut = true;
 	}
 	if (!anyOut) return n;
@@ -68,8 +68,9 @@ __device__ __noinline__ int clip_poly(ClipV* v, int n, int plane)
 
 __device__ __forceinline__ void snap_vertex(double x, double y, double w, double hW, double hH, int32_t& X, int32_t& Y)
 {
-	double sx = (x / w + 1.0) * hW;
-	double sy = (y / w + 1.0) * hH;
+	double iw = 1.0 / w;
+	double sx = (x * iw + 1.0) * hW;
+	double sy = (y * iw + 1.0) * hH;
 	X = (int32_t)(long long)floor(sx * (double)VKR_SUBPIX + 0.5);
 	Y = (int32_t)(long long)floor(sy * (double)VKR_SUBPIX + 0.5);
 }
@@ -121,14 +122,17 @@ __device__ __forceinline__ bool prepare_subtri(const SetupArgs& a, int32_t X0, i
 	return true;
 }
 
-__device__ __forceinline__ void commit_subtri(const SetupArgs& a, uint32_t slot, const SubTri& r, uint2 tiles)
+// countTiles = false leaves the per-tile counting to the caller
+__device__ __forceinline__ bool commit_subtri(const SetupArgs& a, uint32_t slot, const SubTri& r, uint2 tiles, bool countTiles = true)
 {
-	if (slot >= a.recCap) { atomicOr(a.overflow, 1u); return; }
+	if (slot >= a.recCap) { atomicOr(a.overflow, 1u); return false; }
 	a.recs[slot] = r;
 	a.recTiles[slot] = tiles;
+	if (!countTiles) return true;
 	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
 	for (uint32_t ty = ty0; ty <= ty1; ty++)
 		for (uint32_t tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tileCount[ty * a.view.tilesX + tx], 1u);
+	return true;
 }
 
 __device__ __forceinline__ void emit_subtri(const SetupArgs& a, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2,
@@ -147,7 +151,7 @@ __device__ __noinline__ void setup_clipped(const SetupArgs& a, float4 c0, float4
 	v[1].x = c1.x; v[1].y = c1.y; v[1].z = c1.z; v[1].w = c1.w;
 	v[2].x = c2.x; v[2].y = c2.y; v[2].z = c2.z; v[2].w = c2.w;
 	int n = 3;
-	for (int p = 0; p < 5 && n >= 3; p++) n = clip_poly(v, n, p);
+	for (int p = 0; p < 5 && n >= 3; p++) n = clip_poly(v, n, p, a.guard);
 	if (n < 3) return;
 	int32_t X[10], Y[10];
 	for (int i = 0; i < n; i++) snap_vertex(v[i].x, v[i].y, v[i].w, hW, hH, X[i], Y[i]);
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 			const double hW = (double)a.view.W * 0.5, hH = (double)a.view.H * 0.5;
 			// does any vertex violate the near or a guard-band plane?
 			bool needClip = false;
+			const double VKR_GUARD = a.guard;
 			{
 				const float4 c[3] = { c0, c1, c2 };
 #pragma unroll
@@ -219,7 +224,20 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 		uint32_t base = 0;
 		if ((int)lane == leader) base = atomicAdd(a.recCount, (uint32_t)__popcll(mask));
 		base = __shfl(base, leader, 64);
-		if (emit) commit_subtri(a, base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), rec, tiles);
+		const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
+		const bool bigRec = emit && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 8;
+		bool stored = false;
+		if (emit) stored = commit_subtri(a, base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), rec, tiles, !bigRec);
+		// records that touch many tiles: the wave counts them together
+		unsigned long long bmask = __ballot(bigRec && stored);
+		while (bmask) {
+			const int src = __ffsll((long long)bmask) - 1;
+			bmask &= bmask - 1;
+			const uint32_t wx0 = __shfl(tx0, src, 64), wy0 = __shfl(ty0, src, 64);
+			const uint32_t wx1 = __shfl(tx1, src, 64), wy1 = __shfl(ty1, src, 64);
+			const uint32_t w = wx1 - wx0 + 1, cnt = w * (wy1 - wy0 + 1);
+			for (uint32_t k = lane; k < cnt; k += 64) atomicAdd(&a.tileCount[(wy0 + k / w) * a.view.tilesX + (wx0 + k % w)], 1u);
+		}
 	}
 }
 
@@ -260,24 +278,50 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 	}
 }
 
+// One thread per record; a record that touches more than 8 tiles is spread
+// over the whole wavefront.
 __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 {
-	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	uint32_t n = min(*a.recCount, a.recCap);
-	if (r >= n) return;
-	uint2 tr = a.recTiles[r];
-	uint32_t tx0 = tr.x & 0xffffu, ty0 = tr.x >> 16, tx1 = tr.y & 0xffffu, ty1 = tr.y >> 16;
-	uint32_t key = 0;
-	if (a.keys) key = a.recs[r].prim;
-	for (uint32_t ty = ty0; ty <= ty1; ty++)
-		for (uint32_t tx = tx0; tx <= tx1; tx++) {
-			uint32_t tile = ty * a.tilesX + tx;
-			uint32_t idx = a.tileOffset[tile] + atomicAdd(&a.cursor[tile], 1u);
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t n = min(*a.recCount, a.recCap);
+	const bool has = r < n;
+	uint32_t tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0, key = 0;
+	if (has) {
+		const uint2 tr = a.recTiles[r];
+		tx0 = tr.x & 0xffffu; ty0 = tr.x >> 16; tx1 = tr.y & 0xffffu; ty1 = tr.y >> 16;
+		if (a.keys) key = a.recs[r].prim;
+	}
+	const uint32_t nt = has ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0;
+	const bool big = nt > 8;
+	if (has && !big) {
+		for (uint32_t ty = ty0; ty <= ty1; ty++)
+			for (uint32_t tx = tx0; tx <= tx1; tx++) {
+				const uint32_t tile = ty * a.tilesX + tx;
+				const uint32_t idx = a.tileOffset[tile] + atomicAdd(&a.cursor[tile], 1u);
+				if (idx < a.binCap) {
+					a.binList[idx] = r;
+					if (a.keys) a.keys[idx] = key;
+				}
+			}
+	}
+	unsigned long long mask = __ballot(big);
+	const uint32_t lane = threadIdx.x & 63;
+	while (mask) {
+		const int src = __ffsll((long long)mask) - 1;
+		mask &= mask - 1;
+		const uint32_t wr = __shfl(r, src, 64), wkey = __shfl(key, src, 64);
+		const uint32_t wx0 = __shfl(tx0, src, 64), wy0 = __shfl(ty0, src, 64);
+		const uint32_t wx1 = __shfl(tx1, src, 64), wy1 = __shfl(ty1, src, 64);
+		const uint32_t w = wx1 - wx0 + 1, cnt = w * (wy1 - wy0 + 1);
+		for (uint32_t k = lane; k < cnt; k += 64) {
+			const uint32_t tile = (wy0 + k / w) * a.tilesX + (wx0 + k % w);
+			const uint32_t idx = a.tileOffset[tile] + atomicAdd(&a.cursor[tile], 1u);
 			if (idx < a.binCap) {
-				a.binList[idx] = r;
-				if (a.keys) a.keys[idx] = key;
+				a.binList[idx] = wr;
+				if (a.keys) a.keys[idx] = wkey;
 			}
 		}
+	}
 }
 
 // ---------------------------------------------------------------------------

@@ -18,10 +18,28 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float h2f_lo(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)); }
 __device__ __forceinline__ float h2f_hi(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); }
 
+// linear -> sRGB code with two LDS lookups: a hardware log2/exp2 estimate of
+// round(255*OETF(x)) corrected by at most one step against the exact
+// threshold table, so the result equals the table search of vkr_srgb_encode.
+// T points at 257 floats: T[0] = -inf, T[k+1] = threshold k, T[256] = +inf.
+__device__ __forceinline__ uint32_t srgb_encode_fast(const float* T, float x)
+{
+	x = fminf(fmaxf(x, 0.0f), 1.0f);
+	const float e = (x <= 0.0031308f) ? 12.92f * x
+	                                  : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)) - 0.055f;
+	int code = (int)(e * 255.0f + 0.5f);
+	code = min(max(code, 0), 255);
+	// code is right iff T[code] <= x < T[code+1]
+	if (x < T[code]) code--;
+	else if (x >= T[code + 1]) code++;
+	return (uint32_t)code;
+}
+
 __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 {
-	__shared__ float sThresh[256];
-	if (threadIdx.x < 255) sThresh[threadIdx.x] = a.srgbThresh[threadIdx.x];
+	__shared__ float sT[257];
+	if (threadIdx.x < 255) sT[threadIdx.x + 1] = a.srgbThresh[threadIdx.x];
+	if (threadIdx.x == 255) { sT[0] = -__builtin_inff(); sT[256] = __builtin_inff(); }
 	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
 	const uint32_t n = rw * rh;
@@ -61,52 +79,57 @@ __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 	// light-independent terms
 	const float ndv = Nx * Vx + Ny * Vy + Nz * Vz;
 	const float ndvp = fmaxf(ndv, 0.0f);
+	const float ndvp4 = 4.0f * ndvp;
 	const float pir2 = PI * r2;
 	const float om = 1.0f - metal;
-	float f0[3], omf0[3], kd[3], amb[3];
+	float f0[3], omf0[3], kd[3];
 #pragma unroll
 	for (int c = 0; c < 3; c++) {
 		f0[c] = om * 0.04f + metal * alb[c];
 		omf0[c] = 1.0f - f0[c];
 		kd[c] = (alb[c] / PI) * om;
-		amb[c] = 0.03f * alb[c];
 	}
+	// With H = (V+L)/|V+L| and |V| = |L| = 1:  |V+L|^2 = 2(1 + V.L),
+	// N.H = (N.V + N.L)/|V+L|,  V.H = (1 + V.L)/|V+L|.
 	float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll 3
 	for (int i = 0; i < VKR_NUM_LIGHTS_K; i++) {
-		const float Lx0 = a.lightPos[i][0] - Px, Ly0 = a.lightPos[i][1] - Py, Lz0 = a.lightPos[i][2] - Pz;
-		const float d2 = Lx0 * Lx0 + Ly0 * Ly0 + Lz0 * Lz0;
+		const float Lx = a.lightPos[i][0] - Px, Ly = a.lightPos[i][1] - Py, Lz = a.lightPos[i][2] - Pz;
+		const float d2 = Lx * Lx + Ly * Ly + Lz * Lz;
 		const float invd = fast_rsq(d2);
 		const float invd2 = invd * invd;
-		const float Lx = Lx0 * invd, Ly = Ly0 * invd, Lz = Lz0 * invd;
-		float Hx = Vx + Lx, Hy = Vy + Ly, Hz = Vz + Lz;
-		const float invh = fast_rsq(Hx * Hx + Hy * Hy + Hz * Hz);
-		Hx *= invh; Hy *= invh; Hz *= invh;
-		const float ndh = Nx * Hx + Ny * Hy + Nz * Hz;
-		const float ndl = Nx * Lx + Ny * Ly + Nz * Lz;
-		const float vdh = Vx * Hx + Vy * Hy + Vz * Hz;
-		const float ndhp = fmaxf(ndh, 0.0f), ndlp = fmaxf(ndl, 0.0f);
+		const float ndl = (Nx * Lx + Ny * Ly + Nz * Lz) * invd;
+		const float opv = 1.0f + (Vx * Lx + Vy * Ly + Vz * Lz) * invd; // 1 + V.L
+		const float invh = fast_rsq(opv + opv);
+		const float ndhp = fmaxf((ndv + ndl) * invh, 0.0f);
+		const float ndlp = fmaxf(ndl, 0.0f);
+		const float vdh = opv * invh;
 		// D = exp((nh^2-1)/(r^2 nh^2)) / (0.001 + pi r^2 nh^4)
 		const float nh2 = ndhp * ndhp, nh4 = nh2 * nh2;
-		const float ex = (nh2 - 1.0f) * fast_rcp(r2 * nh2);
-		const float ndf = fast_exp2(ex * LOG2E) * fast_rcp(0.001f + pir2 * nh4);
+		const float ex = fast_exp2((nh2 - 1.0f) * LOG2E * fast_rcp(r2 * nh2));
+		// one reciprocal for D's denominator and the BRDF denominator (both >= 0.001)
+		const float rden = fast_rcp((0.001f + pir2 * nh4) * (0.001f + ndvp4 * ndlp));
 		// F = f0 + (1-f0) (1 - v.h)^5
 		const float xx = 1.0f - vdh;
 		const float x2 = xx * xx, x5 = x2 * x2 * xx;
 		// G = min(1, 2 n.h n.v / v.h, 2 n.h n.l / v.h)
-		const float g0 = 2.0f * ndhp * fast_rcp(vdh);
+		const float g0 = (ndhp + ndhp) * fast_rcp(vdh);
 		const float G = fminf(1.0f, fminf(g0 * ndvp, g0 * ndlp));
-		const float spec = ndf * G * fast_rcp(0.001f + 4.0f * ndvp * ndlp);
-		const float w = 10.0f * ndlp;
+		const float spec = ex * G * rden;
+		const float t = 10.0f * ndlp * invd2;
 #pragma unroll
 		for (int c = 0; c < 3; c++) {
 			const float F = f0[c] + omf0[c] * x5;
-			const float br = kd[c] * (1.0f - F) + spec * F;
-			acc[c] += (amb[c] + br * w * a.lightCol[i][c]) * invd2;
+			const float br = kd[c] + F * (spec - kd[c]); // kd (1-F) + spec F
+			acc[c] += br * (a.lightCol[i][c] * t);
 		}
 		acc[3] += invd2;
 	}
-	a.colour[p] = vkr_pack_colour(sThresh, acc[0], acc[1], acc[2], acc[3]);
+	// ambient 0.03*albedo is added per light and attenuated with it (deferredShading.frag:108,115)
+#pragma unroll
+	for (int c = 0; c < 3; c++) acc[c] += 0.03f * alb[c] * acc[3];
+	a.colour[p] = srgb_encode_fast(sT, acc[0]) | (srgb_encode_fast(sT, acc[1]) << 8) | (srgb_encode_fast(sT, acc[2]) << 16) |
+	              (vkr_unorm_encode(vkr_clamp01(acc[3])) << 24);
 }
 
 // overVisRead.frag:7-13: oColor = (0,0.3,0,0.1) + vec4(vec3(stencil/25), 0)

@@ -23,11 +23,12 @@ struct Frag {
 };
 
 // loads the visible fragment of pixel (px,py); returns false if none
-__device__ __forceinline__ bool load_frag(const ResolveArgs& a, unsigned long long key, int px, int py, uint32_t tA, Frag& f)
+template <bool NEEDZ>
+__device__ __forceinline__ bool load_frag(const ResolveArgs& a, int px, int py, uint32_t tA, Frag& f)
 {
 	f.tA = tA;
 	f.i0 = a.sc.tri[3 * (size_t)tA + 0]; f.i1 = a.sc.tri[3 * (size_t)tA + 1]; f.i2 = a.sc.tri[3 * (size_t)tA + 2];
-	if (!vkr_tri_planes(a.clip[f.i0], a.clip[f.i1], a.clip[f.i2], a.view.W, a.view.H, f.pl)) return false;
+	if (!vkr_tri_planes<NEEDZ>(a.clip[f.i0], a.clip[f.i1], a.clip[f.i2], a.view.W, a.view.H, f.pl)) return false;
 	vkr_bary_at(f.pl, px, py, f.b);
 	float2 t0 = make_float2(a.sc.uv[2 * (size_t)f.i0], a.sc.uv[2 * (size_t)f.i0 + 1]);
 	float2 t1 = make_float2(a.sc.uv[2 * (size_t)f.i1], a.sc.uv[2 * (size_t)f.i1 + 1]);
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void k_resolve_gbuf(ResolveArgs a)
 	// attachment clears 0.1 (main/main.cpp:3843-3851): half(0.1) = 0x2E66
 	uint2 gn = make_uint2(0x2E662E66u, 0x2E662E66u), ga = gn;
 	Frag f;
-	if (prim != VKR_NO_PRIM && load_frag(a, 0, px, py, prim, f)) {
+	if (prim != VKR_NO_PRIM && load_frag<false>(a, px, py, prim, f)) {
 		const MatInfo& mi = a.sc.mat[f.mat];
 		float nm[4], alb[4], me[4], ro[4], N[3];
 		vkr_trilinear(a.sc, a.sc.tex[mi.tex[4]], f.uv[0], f.uv[1], f.d, nm);
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 	// clear colour (0.1,0.1,0.1,1), main/main.cpp:3988-3991
 	uint32_t colour = vkr_pack_colour(a.sc.srgbThresh, 0.1f, 0.1f, 0.1f, 1.0f);
 	Frag f;
-	if (prim != VKR_NO_PRIM && load_frag(a, 0, px, py, prim, f)) {
+	if (prim != VKR_NO_PRIM && load_frag<false>(a, px, py, prim, f)) {
 		const MatInfo& mi = a.sc.mat[f.mat];
 		float nm[4], alb[4], me[4], ro[4], N[3], P[3];
 		vkr_trilinear(a.sc, a.sc.tex[mi.tex[4]], f.uv[0], f.uv[1], f.d, nm);
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void k_resolve_debug(ResolveArgs a)
 		const uint32_t tA = a.useOrderB ? a.sc.orderB[a.sc.nTri + prim] : prim;
 		Frag f;
 		const int mode = a.debugMode;
-		if (load_frag(a, 0, px, py, tA, f)) {
+		if (load_frag<true>(a, px, py, tA, f)) {
 			float c[4] = { 0, 0, 0, 1.0f };
 			if (mode == 3) {
 				float v = linearise_depth(depth) / 100.0f;

@@ -96,7 +96,7 @@ struct vkr_context {
 	float* dThresh = nullptr; // 255
 	float hDecode[256], hThresh[255];
 	// geometry scratch
-	DevBuf clip, recs, recTiles, counters, tileCount, tileOffset, cursor, binList, binKeys, binList2, binKeys2, sortTemp;
+	DevBuf clip, recs, recTiles, counters, tileCount, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
 	uint32_t recCap = 0, binCap = 0;
 	double capScale = 1.0;
 	// frame buffers
@@ -121,6 +121,7 @@ struct vkr_scene {
 	SceneDev dev;
 	std::vector<HostTex> htex;
 	uint64_t nTri = 0, nVert = 0, texelCount = 0;
+	bool anyAlphaTest = false; // some material's alpha texture can fail the 0.5 test
 };
 
 // ---------------------------------------------------------------------------
@@ -316,7 +317,7 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf* bufs[] = { &c->clip, &c->recs, &c->recTiles, &c->counters, &c->tileCount, &c->tileOffset, &c->cursor, &c->binList,
+	DevBuf* bufs[] = { &c->clip, &c->recs, &c->recTiles, &c->counters, &c->tileCount, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
 		&c->binKeys, &c->binList2, &c->binKeys2, &c->sortTemp, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
 		&c->colour2, &c->stencil, &c->mip, &c->shadow };
 	for (DevBuf* b : bufs) b->release();
@@ -565,6 +566,7 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 			lowAlpha[at] = low;
 		}
 		mi.alphaTest = (uint32_t)lowAlpha[at];
+		if (mi.alphaTest) s->anyAlphaTest = true;
 	}
 	if ((rc = upload(s->mat, minfo.data(), minfo.size() * sizeof(MatInfo)))) return fail(rc);
 	{
@@ -649,6 +651,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if ((rc = c->tileCount.ensure((size_t)nTiles * 4))) return rc;
 	if ((rc = c->tileOffset.ensure((size_t)(nTiles + 1) * 4))) return rc;
 	if ((rc = c->cursor.ensure((size_t)nTiles * 4))) return rc;
+	if ((rc = c->tileFlags.ensure((size_t)nTiles * 4))) return rc;
 	if ((rc = c->binList.ensure((size_t)binCap * 4))) return rc;
 	if (g.keys && (rc = c->binKeys.ensure((size_t)binCap * 4))) return rc;
 	c->recCap = recCap; c->binCap = binCap;
@@ -665,6 +668,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 		a.sc = s->dev; a.view = g.view; a.clip = c->clip.as<float4>();
 		a.first = g.first; a.count = g.count; a.cullOpaque = g.cullOpaque; a.cullAlpha = g.cullAlpha;
 		a.useOrderB = g.useOrderB; a.alphaTest = g.alphaTest; a.shadow = g.shadow;
+		a.guard = vkr_guard_band(g.view.W, g.view.H);
 		a.recs = c->recs.as<SubTri>(); a.recTiles = c->recTiles.as<uint2>(); a.recCap = recCap;
 		a.recCount = counters; a.tileCount = c->tileCount.as<uint32_t>(); a.overflow = counters + 1;
 		vkr_launch_setup(c->stream, a);
@@ -695,6 +699,7 @@ static void fill_raster_args(vkr_context* c, const vkr_scene* s, const ViewDev& 
 	r.sc = s->dev; r.view = view; r.clip = c->clip.as<float4>(); r.recs = c->recs.as<SubTri>();
 	r.tileOffset = c->tileOffset.as<uint32_t>(); r.binList = c->binList.as<uint32_t>(); r.binCap = c->binCap;
 	r.vis = nullptr; r.depthOut = nullptr; r.countOut = nullptr;
+	r.alphaTiles = c->tileFlags.as<uint32_t>(); r.alphaTileCount = c->counters.as<uint32_t>() + 2; r.alphaPass = 0;
 }
 
 static int copy_out(vkr_context* c, void* dst, const void* src, size_t bytes)
@@ -743,6 +748,7 @@ static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 			RasterArgs r;
 			fill_raster_args(c, s, view, r);
 			r.vis = c->vis.as<unsigned long long>();
+			r.alphaPass = s->anyAlphaTest ? 1 : 0;
 			vkr_launch_raster(c->stream, RASTER_VIS, r);
 		}
 		StageTimer t(c, ST_RESOLVE_FORWARD);
@@ -800,6 +806,7 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 			RasterArgs r;
 			fill_raster_args(c, s, view, r);
 			r.vis = c->vis.as<unsigned long long>();
+			r.alphaPass = s->anyAlphaTest ? 1 : 0;
 			vkr_launch_raster(c->stream, RASTER_VIS, r);
 		}
 		{

@@ -10,11 +10,15 @@
 #define VKR_TILE 32            // screen tile edge in pixels
 #define VKR_TILE_PIX (VKR_TILE * VKR_TILE)
 #define VKR_SUBPIX 256         // 8 sub-pixel bits
-#define VKR_GUARD 64.0         // guard band in NDC half-widths
 #define VKR_MAX_LEVELS 16
 #define VKR_MAX_SUBTRI 6       // a triangle clipped by near + 4 guard planes: <= 8 vertices
 #define VKR_NUM_LIGHTS_K 21     // deferredShading.frag:5
 #define VKR_NO_PRIM 0xffffffffu
+#define VKR_ALPHA_SLICES 1      // workgroups a tile's alpha-tested bin entries are spread over
+
+// Guard band in NDC half-widths: small enough that the snapped coordinates
+// keep every edge function below 2^53, so edges are exact in double.
+static inline double vkr_guard_band(uint32_t W, uint32_t H) { return ((W > H ? W : H) <= 4096u) ? 32.0 : 8.0; }
 
 struct Mat4 { float m[16]; };  // column-major, glm::mat4
 
@@ -173,7 +177,8 @@ struct TriPlanes {
 	double Az, Bz, Cz;
 };
 
-// returns false for a degenerate (zero-determinant) triangle
+// returns false for a degenerate (zero-determinant) triangle; NEEDZ = also the depth plane
+template <bool NEEDZ = true>
 __device__ __forceinline__ bool vkr_tri_planes(const float4 c0, const float4 c1, const float4 c2, uint32_t W, uint32_t H,
                                                TriPlanes& pl)
 {
@@ -189,10 +194,15 @@ __device__ __forceinline__ bool vkr_tri_planes(const float4 c0, const float4 c1,
 	pl.a[2] = hy0 * hw1 - hy1 * hw0; pl.b[2] = hx1 * hw0 - hx0 * hw1; pl.c[2] = hx0 * hy1 - hx1 * hy0;
 	double det = (hx0 * pl.a[0] + hy0 * pl.b[0]) + hw0 * pl.c[0];
 	if (det == 0.0 || !(det == det)) return false;
-	double z0 = c0.z, z1 = c1.z, z2 = c2.z;
-	pl.Az = ((z0 * pl.a[0] + z1 * pl.a[1]) + z2 * pl.a[2]) / det;
-	pl.Bz = ((z0 * pl.b[0] + z1 * pl.b[1]) + z2 * pl.b[2]) / det;
-	pl.Cz = ((z0 * pl.c[0] + z1 * pl.c[1]) + z2 * pl.c[2]) / det;
+	if (NEEDZ) {
+		double z0 = c0.z, z1 = c1.z, z2 = c2.z;
+		double idet = 1.0 / det;
+		pl.Az = ((z0 * pl.a[0] + z1 * pl.a[1]) + z2 * pl.a[2]) * idet;
+		pl.Bz = ((z0 * pl.b[0] + z1 * pl.b[1]) + z2 * pl.b[2]) * idet;
+		pl.Cz = ((z0 * pl.c[0] + z1 * pl.c[1]) + z2 * pl.c[2]) * idet;
+	} else {
+		pl.Az = pl.Bz = pl.Cz = 0.0;
+	}
 	return true;
 }
 
@@ -208,8 +218,8 @@ __device__ __forceinline__ void vkr_bary_at(const TriPlanes& pl, int px, int py,
 	double l0 = fma(pl.a[0], sx, fma(pl.b[0], sy, pl.c[0]));
 	double l1 = fma(pl.a[1], sx, fma(pl.b[1], sy, pl.c[1]));
 	double l2 = fma(pl.a[2], sx, fma(pl.b[2], sy, pl.c[2]));
-	double s = (l0 + l1) + l2;
-	b[0] = (float)(l0 / s); b[1] = (float)(l1 / s); b[2] = (float)(l2 / s);
+	double is = 1.0 / ((l0 + l1) + l2);
+	b[0] = (float)(l0 * is); b[1] = (float)(l1 * is); b[2] = (float)(l2 * is);
 }
 
 __device__ __forceinline__ float vkr_interp(const float b[3], float f0, float f1, float f2)
@@ -327,6 +337,37 @@ __device__ __forceinline__ void vkr_trilinear(const SceneDev& sc, const TexInfo&
 	vkr_bilinear(sc, t, lv + 1, u, v, b);
 #pragma unroll
 	for (int c = 0; c < 4; c++) out[c] = vkr_lerp(a[c], b[c], fr);
+}
+
+// Alpha channel only (the alpha test needs nothing else): same arithmetic as
+// the .a component of vkr_bilinear / vkr_trilinear.
+__device__ __forceinline__ float vkr_bilinear_alpha(const SceneDev& sc, const TexInfo& t, int level, float u, float v)
+{
+	int w = t.w[level], h = t.h[level];
+	float x = u * (float)w - 0.5f;
+	float y = v * (float)h - 0.5f;
+	if (!(fabsf(x) < 1.0e9f)) x = 0.0f;
+	if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
+	float x0f = floorf(x), y0f = floorf(y);
+	float fx = x - x0f, fy = y - y0f;
+	int x0 = vkr_wrap((int)x0f, w), x1 = vkr_wrap((int)x0f + 1, w);
+	int y0 = vkr_wrap((int)y0f, h), y1 = vkr_wrap((int)y0f + 1, h);
+	const uint32_t* base = sc.texels + t.offset[level];
+	float t00 = (float)(base[(uint32_t)y0 * w + (uint32_t)x0] >> 24) / 255.0f;
+	float t10 = (float)(base[(uint32_t)y0 * w + (uint32_t)x1] >> 24) / 255.0f;
+	float t01 = (float)(base[(uint32_t)y1 * w + (uint32_t)x0] >> 24) / 255.0f;
+	float t11 = (float)(base[(uint32_t)y1 * w + (uint32_t)x1] >> 24) / 255.0f;
+	return vkr_lerp(vkr_lerp(t00, t10, fx), vkr_lerp(t01, t11, fx), fy);
+}
+
+__device__ __forceinline__ float vkr_trilinear_alpha(const SceneDev& sc, const TexInfo& t, float u, float v, const float d[4])
+{
+	int lv; float fr;
+	vkr_lod_split(vkr_rho2(t, d), t.levels - 1, lv, fr);
+	if (fr == 0.0f) return vkr_bilinear_alpha(sc, t, lv, u, v);
+	float a = vkr_bilinear_alpha(sc, t, lv, u, v);
+	float b = vkr_bilinear_alpha(sc, t, lv + 1, u, v);
+	return vkr_lerp(a, b, fr);
 }
 
 // TBN decode (default.vert:57-81): GLSL mat3 column-major m[c*3+r]

@@ -11,6 +11,7 @@ struct SetupArgs {
 	int useOrderB;             // prim = file-order rank (passes that draw every mesh in file order)
 	int alphaTest;             // the pass's fragment shader discards on alpha < 0.5
 	int shadow;                // depth bias of the shadow pipeline
+	double guard;              // guard band, vkr_guard_band(view.W, view.H)
 	SubTri* recs;
 	uint2* recTiles;
 	uint32_t recCap;
@@ -45,6 +46,9 @@ struct RasterArgs {
 	unsigned long long* vis; // RASTER_VIS: rect-sized visibility buffer
 	float* depthOut;         // RASTER_SHADOW: rect-sized depth
 	uint8_t* countOut;       // RASTER_COUNT: rect-sized saturating counter
+	uint32_t* alphaTiles;    // RASTER_VIS: list of the tiles whose bin holds alpha-tested sub-triangles
+	uint32_t* alphaTileCount; // its length (zeroed by the caller)
+	int alphaPass;           // RASTER_VIS: run the alpha-tested second pass
 };
 
 struct OvershadeArgs {

@@ -182,12 +182,12 @@ def _add_material(rng, textures, materials, size, tint, alpha_mask=False):
     return len(materials) - 1
 
 
-def foliage_cluster(rng, center, count, size, material):
+def foliage_cluster(rng, center, count, size, material, spread=0.8):
     """Double-sided alpha-masked quads with random orientations."""
     meshes = []
     pos, nrm, uv, tan, idx = [], [], [], [], []
     for q in range(count):
-        c = np.asarray(center) + rng.normal(0, 0.8, 3) * np.array([1.0, 0.6, 1.0])
+        c = np.asarray(center) + rng.normal(0, spread, 3) * np.array([1.0, 0.6, 1.0])
         a = rng.random() * 2 * np.pi
         tilt = (rng.random() - 0.5) * 0.8
         du = np.array([np.cos(a), 0.0, np.sin(a)]) * size
@@ -291,5 +291,5 @@ def proxy_scene(detail=1.0, tex_size=1024, seed=PROXY_SEED, materials_total=48, 
     # foliage: three clusters of alpha-masked quads
     fcount = max(4, int(round(500 * detail)))
     for i, c in enumerate(((-6.0, -3.5, -8.0), (6.5, -3.5, -30.0), (-5.0, -3.5, -55.0)) if foliage else ()):
-        meshes += foliage_cluster(rng, c, fcount, 1.4, alpha[i % len(alpha)])
+        meshes += foliage_cluster(rng, c, fcount, 0.6, alpha[i % len(alpha)], spread=1.3)
     return PackedScene(textures, materials, meshes)
