@@ -178,6 +178,12 @@ VKR_API int vkr_scene_create(vkr_context* ctx, const vkr_scene_desc* desc, vkr_s
  * main/baked_model.cpp:70-174) and the PNG textures it names. */
 VKR_API int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** out);
 VKR_API void vkr_scene_destroy(vkr_scene* scene);
+/* Host-only: decodes one PNG the way the reference's texture loader does,
+ * stbi_load(path, &w, &h, &c, 4) after stbi_set_flip_vertically_on_load(1)
+ * (utils/vkimage.cpp:62-65): 8-bit RGBA, bottom row first.  *rgba8 is
+ * allocated by the library; release it with vkr_free(). */
+VKR_API int vkr_decode_png_file(const char* path, uint8_t** rgba8, uint32_t* width, uint32_t* height);
+VKR_API void vkr_free(void* p);
 /* number of triangles / vertices held by the scene */
 VKR_API int vkr_scene_stats(const vkr_scene* scene, uint64_t* triangles, uint64_t* vertices, uint64_t* texture_bytes);
 /* Reads mip level `level` of texture `tex` back (RGBA8); for parity tests of

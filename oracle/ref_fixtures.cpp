@@ -10,6 +10,7 @@
 // usage: ref_fixtures matrices            -> JSON on stdout
 //        ref_fixtures tangents            -> JSON on stdout
 //        ref_fixtures loadmodel <file>    -> JSON on stdout
+//        ref_fixtures stb <png>...        -> JSON on stdout (stbi_load(...,4) flipped, as utils/vkimage.cpp:62-65)
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -19,6 +20,8 @@
 #include <glm/glm.hpp>
 #include <glm/gtc/matrix_transform.hpp>
 #include <glm/gtx/transform.hpp>
+
+#include <stb_image.h>
 
 #include "../utils/angle.hpp"
 #include "../main-bake/index_mesh.hpp"
@@ -166,11 +169,33 @@ static int do_loadmodel(const char* path)
 	return 0;
 }
 
+static int do_stb(int n, char** files)
+{
+	stbi_set_flip_vertically_on_load(1);
+	std::printf("{\n");
+	for (int i = 0; i < n; i++) {
+		int w = 0, h = 0, c = 0;
+		stbi_uc* data = stbi_load(files[i], &w, &h, &c, 4);
+		const char* base = std::strrchr(files[i], '/');
+		base = base ? base + 1 : files[i];
+		if (!data) { std::printf("  \"%s\": null%s\n", base, i + 1 == n ? "" : ","); continue; }
+		std::printf("  \"%s\": {\"width\": %d, \"height\": %d, \"file_channels\": %d, \"fnv1a\": \"%016llx\", \"first\": [", base, w, h, c,
+			(unsigned long long)fnv1a(data, (std::size_t)w * h * 4));
+		int m = w * h * 4 < 32 ? w * h * 4 : 32;
+		for (int k = 0; k < m; k++) std::printf("%u%s", data[k], k + 1 == m ? "" : ", ");
+		std::printf("]}%s\n", i + 1 == n ? "" : ",");
+		stbi_image_free(data);
+	}
+	std::printf("}\n");
+	return 0;
+}
+
 int main(int argc, char** argv)
 try {
 	if (argc >= 2 && 0 == std::strcmp(argv[1], "matrices")) return do_matrices();
 	if (argc >= 2 && 0 == std::strcmp(argv[1], "tangents")) return do_tangents();
 	if (argc >= 3 && 0 == std::strcmp(argv[1], "loadmodel")) return do_loadmodel(argv[2]);
+	if (argc >= 3 && 0 == std::strcmp(argv[1], "stb")) return do_stb(argc - 2, argv + 2);
 	std::fprintf(stderr, "usage: ref_fixtures matrices|tangents|loadmodel <file>\n");
 	return 2;
 } catch (std::exception const& e) {

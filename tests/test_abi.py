@@ -1,0 +1,62 @@
+"""The C-ABI library loads and exports every function include/vkr_renderer.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared():
+    src = open(os.path.join(ROOT, "include", "vkr_renderer.h")).read()
+    return sorted(set(re.findall(r"VKR_API[^;(]*?\b(vkr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_boundary():
+    names = declared()
+    for must in ("vkr_context_create", "vkr_scene_create", "vkr_scene_load", "vkr_render", "vkr_wait", "vkr_last_error",
+                 "vkr_update_scene_uniforms", "vkr_update_depth_mvp_uniforms"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from vulkanrenderer_amd import renderer
+    L = C.CDLL(renderer.LIB_PATH)
+    for n in declared():
+        assert hasattr(L, n), "libvkr_hip.so does not export %s" % n
+    assert sorted(renderer.EXPORTS) == declared()
+
+
+def test_struct_layouts_match_the_reference_blocks():
+    from vulkanrenderer_amd import abi
+    # std140 sizes of main/main.cpp:205-227
+    assert C.sizeof(abi.SceneUniform) == 208 and abi.SceneUniform.projection.offset == 64
+    assert abi.SceneUniform.projCam.offset == 128 and abi.SceneUniform.camPos.offset == 192
+    assert C.sizeof(abi.LightUniform) == 32 and C.sizeof(abi.MultipleLights) == 21 * 32 and C.sizeof(abi.DepthMVP) == 64
+    assert C.sizeof(abi.MaterialDesc) == 24  # BakedMaterialInfo, six u32
+
+
+def test_null_arguments_fail_cleanly():
+    from vulkanrenderer_amd import renderer
+    L = renderer.lib()
+    assert L.vkr_render(None, None, None, None) != 0
+    assert b"NULL" in L.vkr_last_error()
+    assert L.vkr_wait(None) != 0
+    assert L.vkr_scene_stats(None, None, None, None) != 0
+    L.vkr_context_destroy(None)
+    L.vkr_scene_destroy(None)
+    assert L.vkr_stage_count() >= 10 and L.vkr_stage_name(0) == b"k_xform"
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    """Without a GPU the context cannot be created: there is no CPU path behind the ABI."""
+    import ctypes
+    from vulkanrenderer_amd import renderer
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    assert renderer.lib().vkr_context_create(0, ctypes.byref(h)) != 0
+    assert not h.value
+    with pytest.raises(renderer.VkrError):
+        renderer.Context(0)

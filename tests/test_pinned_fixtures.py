@@ -1,0 +1,184 @@
+"""Everything the reference's own compilable sources can pin, checked against
+fixtures generated from those sources (oracle/ref_fixtures.cpp, tests/make_golden.py):
+glm matrix arithmetic of the uniform blocks, the TBN quaternion packer, the
+baked-model file format, the PNG decode the texture loader performs.
+Both the oracle's restatement and the product's host code are held to them."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.array(list(a), np.float32).view(np.uint32)
+
+
+def f32(u):
+    return np.array(u, np.uint32).view(np.float32)
+
+
+def c16(v):
+    return (C.c_float * 16)(*[float(x) for x in v])
+
+
+def fnv1a(b):
+    h = 1469598103934665603
+    for x in b:
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+@pytest.fixture(scope="module")
+def mats():
+    return json.load(open(os.path.join(GOLD, "ref_matrices.json")))
+
+
+def _scene_uniform_impls():
+    from oracle import oracle
+    from vulkanrenderer_amd import renderer
+    return {"oracle": oracle.lib().ora_update_scene_uniforms, "product": renderer.lib().vkr_update_scene_uniforms}
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_scene_uniforms_bit_exact(mats, impl):
+    """update_scene_uniforms (main/main.cpp:3681-3693) for 4 poses x 4 extents."""
+    from vulkanrenderer_amd import abi
+    fn = _scene_uniform_impls()[impl]
+    assert len(mats["scene"]) == 16
+    for e in mats["scene"]:
+        su = abi.SceneUniform()
+        fn(C.byref(su), e["width"], e["height"], c16(f32(e["camera2world"])))
+        for k in ("camera", "projection", "projCam"):
+            assert np.array_equal(bits(getattr(su, k)), np.array(e[k], np.uint32)), (impl, e["pose"], e["width"], k)
+        c2w = f32(e["camera2world"])
+        assert list(su.camPos) == [c2w[12], c2w[13], c2w[14], 1.0]
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_depth_mvp_bit_exact(mats, impl):
+    """update_depth_mvp_uniforms (main/main.cpp:3699-3707) including the 90-radian fovy."""
+    from oracle import oracle
+    from vulkanrenderer_amd import abi, renderer
+    fn = oracle.lib().ora_update_depth_mvp_uniforms if impl == "oracle" else renderer.lib().vkr_update_depth_mvp_uniforms
+    d = abi.DepthMVP()
+    fn(C.byref(d), (C.c_float * 4)(-0.2972, 7.3100, -11.9532, 0.0))
+    assert np.array_equal(bits(d.depthMVP), np.array(mats["depth"]["depthMVP"], np.uint32))
+    # tan(90 rad / 2) = 1.6198, not tan(45 deg) = 1
+    assert abs(f32(mats["depth"]["depthProjection"])[0] - 1.0 / np.tan(45.0)) < 1e-6
+
+
+def test_inverse_matches_glm(mats):
+    """mat4 inverse used by the deferred pass's posFromDepth (deferredShading.frag:36)."""
+    from oracle import oracle
+    L = oracle.lib()
+    for e in mats["scene"]:
+        for k, src in (("invCamera", "camera"), ("invProjection", "projection")):
+            out = (C.c_float * 16)()
+            L.ora_mat4_inverse(c16(f32(e[src])), out)
+            assert np.array_equal(bits(out), np.array(e[k], np.uint32))
+
+
+def test_default_lights_table():
+    """main/main.cpp:1313-1352."""
+    from oracle import oracle
+    from vulkanrenderer_amd import abi, renderer
+    res = []
+    for fn in (oracle.lib().ora_default_lights, renderer.lib().vkr_default_lights):
+        f, m = abi.LightUniform(), abi.MultipleLights()
+        fn(C.byref(f), C.byref(m))
+        res.append(bytes(f) + bytes(m))
+        assert list(f.lightPos) == [np.float32(-0.2972), np.float32(7.31), np.float32(-11.9532), 0.0]
+        assert list(m.light[18].lightPos) == [0.0, np.float32(-4.1), -76.0, 0.0]
+        assert list(m.light[20].lightColour) == [np.float32(0.9882), np.float32(0.4549), np.float32(0.0196), 1.0]
+    assert res[0] == res[1]
+
+
+def test_make_uniforms_oracle_equals_product():
+    from oracle import oracle
+    from vulkanrenderer_amd import renderer
+    from conftest import pose_matrix
+    for pose in (pose_matrix(), pose_matrix(1, -2, -30, 0.7, -0.2)):
+        for (w, h) in ((1280, 720), (3840, 2160), (33, 17)):
+            assert bytes(oracle.make_uniforms(w, h, pose, 3)) == bytes(renderer.make_uniforms(w, h, pose, 3))
+
+
+def test_tbn_packer_matches_make_indexed_mesh():
+    """main-bake/index_mesh.cpp:178-220 run on a 30-vertex mesh through tgen."""
+    from oracle import oracle
+    from vulkanrenderer_amd import baked_model
+    t = json.load(open(os.path.join(GOLD, "ref_tangents.json")))
+    N = f32([v["normal"] for v in t["vertices"]])
+    T = f32([v["tangent"] for v in t["vertices"]])
+    P = np.array([v["packed"] for v in t["vertices"]], np.uint32)
+    assert len(P) == 30 and len(set(int(p) >> 30 for p in P)) >= 2  # more than one "largest component" case
+    assert np.array_equal(baked_model.pack_tbn(T, N), P)
+    for i in range(len(P)):
+        assert oracle.pack_tbn(T[i, :3] * T[i, 3], N[i]) == P[i]
+        m = oracle.decode_tbn(int(P[i]))  # default.vert:57-81
+        assert np.abs(m[:, 2] - N[i]).max() < 6e-3 and np.abs(m[:, 0] - T[i, :3] * T[i, 3]).max() < 6e-3  # 10-bit truncation
+
+
+def test_writer_reproduces_golden_file(tmp_path):
+    """The writer's bytes are the committed file, which the reference's
+    load_baked_model accepted (ref_loadmodel.json is its dump)."""
+    from vulkanrenderer_amd import baked_model, scenes
+    sc = scenes.micro_scene()
+    tex = [("micro_tex/t%02d.png" % i, t["space"], t["channels"]) for i, t in enumerate(sc.textures)]
+    p = str(tmp_path / "m.comp5892mesh")
+    baked_model.write_baked_model(p, tex, sc.materials, sc.meshes)
+    assert open(p, "rb").read() == open(os.path.join(GOLD, "micro.comp5892mesh"), "rb").read()
+
+
+def test_reader_agrees_with_reference_loader():
+    from vulkanrenderer_amd import baked_model
+    ref = json.load(open(os.path.join(GOLD, "ref_loadmodel.json")))
+    tex, mats_, meshes, trailing = baked_model.read_baked_model(os.path.join(GOLD, "micro.comp5892mesh"))
+    assert trailing == 0
+    assert [(os.path.basename(p), s, c) for p, s, c in tex] == [(os.path.basename(t["path"]), t["space"], t["channels"]) for t in ref["textures"]]
+    assert [list(m) for m in mats_] == ref["materials"]
+    assert len(meshes) == len(ref["meshes"])
+    for m, r in zip(meshes, ref["meshes"]):
+        assert (m["materialId"], len(m["positions"]), len(m["indices"])) == (r["materialId"], r["V"], r["I"])
+        for k in ("positions", "normals", "texcoords", "tangents", "tangentsComp", "indices"):
+            assert fnv1a(m[k].tobytes()) == r[k], k
+
+
+def test_reader_rejects_bad_files(tmp_path):
+    from vulkanrenderer_amd import baked_model
+    data = open(os.path.join(GOLD, "micro.comp5892mesh"), "rb").read()
+    for name, blob in (("magic", b"X" + data[1:]), ("variant", data[:16] + b"default".ljust(16, b"\0") + data[32:]),
+                       ("short", data[: len(data) // 2])):
+        p = str(tmp_path / name)
+        open(p, "wb").write(blob)
+        with pytest.raises(baked_model.BakedModelError):
+            baked_model.read_baked_model(p)
+    p = str(tmp_path / "trail")
+    open(p, "wb").write(data + b"\0\0")
+    assert baked_model.read_baked_model(p)[3] == 2  # the reference only prints a note (main/baked_model.cpp:170-171)
+
+
+@pytest.mark.parametrize("fixture,folder", [("ref_stb.json", "png"), ("ref_stb_micro.json", "micro_tex")])
+def test_png_decode_matches_stb(fixture, folder):
+    """stbi_load(path,...,4) + vertical flip (utils/vkimage.cpp:62-65) on every PNG colour type / depth."""
+    from vulkanrenderer_amd import renderer
+    ref = json.load(open(os.path.join(GOLD, fixture)))
+    assert len(ref) >= 9
+    for name, r in ref.items():
+        a = renderer.decode_png(os.path.join(GOLD, folder, name))
+        assert a.shape == (r["height"], r["width"], 4)
+        assert a.reshape(-1)[: len(r["first"])].tolist() == r["first"]
+        assert fnv1a(a.tobytes()) == r["fnv1a"], name
+
+
+def test_png_decode_errors(tmp_path):
+    from vulkanrenderer_amd import renderer
+    with pytest.raises(renderer.VkrError):
+        renderer.decode_png(str(tmp_path / "missing.png"))
+    p = str(tmp_path / "bad.png")
+    open(p, "wb").write(b"not a png at all")
+    with pytest.raises(renderer.VkrError):
+        renderer.decode_png(p)

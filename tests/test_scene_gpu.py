@@ -1,0 +1,188 @@
+"""GPU tests of the scene hand-off (vkr_scene_create / vkr_scene_load), the GPU
+mip-chain builder, error behaviour, and parity + size-independent properties
+on the SunTemple-proxy scene."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import IDENTITY, pose_matrix
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vulkanrenderer_amd import renderer
+    c = renderer.Context(0)
+    yield c
+    c.close()
+
+
+def params(W, H, pose=IDENTITY, shadow=256, rect=None, **kw):
+    from vulkanrenderer_amd import abi, renderer
+    u = renderer.make_uniforms(W, H, pose, kw.get("debug", 1))
+    return abi.make_params(W, H, u, shadow_size=shadow, rect=rect, **kw)
+
+
+def test_mip_chain_matches_vkcmdblit_restatement(ctx, micro, micro_oracle):
+    """k_mip_level against the oracle's linear-blit mip chain (utils/vkimage.cpp:163-216), every texture and level."""
+    from vulkanrenderer_amd import renderer
+    sc = renderer.Scene(ctx, micro)
+    for t in range(len(micro.textures)):
+        lv = 0
+        while True:
+            try:
+                ref = micro_oracle.texture_level(t, lv)
+            except IndexError:
+                break
+            assert np.array_equal(sc.texture_level(t, lv), ref), "texture %d level %d" % (t, lv)
+            lv += 1
+        assert lv == int(np.log2(micro.textures[t]["rgba8"].shape[0])) + 1
+    sc.close()
+
+
+def test_mip_chain_odd_sizes(ctx):
+    from oracle import oracle
+    from vulkanrenderer_amd import abi, renderer
+    rng = np.random.default_rng(4)
+    tex = [dict(rgba8=rng.integers(0, 256, (6, 20, 4), dtype=np.uint8), space=1, channels=4),
+           dict(rgba8=rng.integers(0, 256, (33, 7, 4), dtype=np.uint8), space=0, channels=4),
+           dict(rgba8=rng.integers(0, 256, (1, 1, 4), dtype=np.uint8), space=1, channels=4)]
+    ps = abi.PackedScene(tex, [(0, 1, 1, 0xFFFFFFFF, 1, 0)], [])
+    sc, osc = renderer.Scene(ctx, ps), oracle.OracleScene(ps)
+    for t, n in ((0, 5), (1, 6), (2, 1)):
+        for lv in range(n):
+            assert np.array_equal(sc.texture_level(t, lv), osc.texture_level(t, lv))
+        with pytest.raises(renderer.VkrError):
+            sc.texture_level(t, n)
+    sc.close()
+
+
+def test_scene_load_equals_scene_create(ctx, micro):
+    """The .comp5892mesh + PNG path gives the same frames as handing the arrays over."""
+    from vulkanrenderer_amd import renderer
+    a = renderer.Scene(ctx, micro)
+    b = renderer.Scene(ctx, path=os.path.join(GOLD, "micro.comp5892mesh"))
+    assert a.stats() == b.stats()
+    for kw in (dict(deferred=True), dict(debug=1), dict(debug=2), dict(debug=6)):
+        p = params(120, 68, pose_matrix(0.5, -0.3, -2.0, 0.4, -0.15), **kw)
+        ra, rb = a.render(p), b.render(p)
+        for k in ra:
+            assert np.array_equal(ra[k], rb[k]), k
+    a.close(); b.close()
+
+
+def test_errors(ctx, micro, tmp_path):
+    from vulkanrenderer_amd import abi, renderer
+    with pytest.raises(renderer.VkrError, match="unable to open"):
+        renderer.Scene(ctx, path=str(tmp_path / "nope.comp5892mesh"))
+    bad = tmp_path / "bad.comp5892mesh"
+    bad.write_bytes(b"\0\0COMP5892Mmesh\0" + b"default".ljust(16, b"\0"))
+    with pytest.raises(renderer.VkrError, match="variant"):
+        renderer.Scene(ctx, path=str(bad))
+    m = dict(micro.meshes[0])
+    m["indices"] = m["indices"].copy()
+    m["indices"][2] = 10 ** 6
+    with pytest.raises(renderer.VkrError, match="index"):
+        renderer.Scene(ctx, abi.PackedScene(micro.textures, micro.materials, [m]))
+    with pytest.raises(renderer.VkrError, match="texture"):
+        renderer.Scene(ctx, abi.PackedScene(micro.textures, [(0, 1, 2, 0xFFFFFFFF, 999, 0)], []))
+    sc = renderer.Scene(ctx, micro)
+    with pytest.raises(renderer.VkrError, match="rectangle"):
+        sc.render(params(64, 36, rect=(0, 0, 65, 36), deferred=True))
+    with pytest.raises(renderer.VkrError, match="extent"):
+        sc.render(params(0, 36, deferred=True))
+    sc.close()
+
+
+def test_empty_scene_renders_clear_colour(ctx, micro):
+    from vulkanrenderer_amd import abi, renderer
+    sc = renderer.Scene(ctx, abi.PackedScene(micro.textures, micro.materials, []))
+    r = sc.render(params(40, 24, deferred=True))
+    assert np.all(r["rgba8"] == np.array([89, 89, 89, 26], np.uint8)) and np.all(r["tri_id"] == 0xFFFFFFFF)
+    r = sc.render(params(40, 24, debug=5))
+    assert np.all(r["stencil"] == 0)
+    sc.close()
+
+
+def test_frames_in_flight(ctx, micro):
+    """vkr_render is asynchronous; several frames may be queued before the fence."""
+    from vulkanrenderer_amd import abi, renderer
+    sc = renderer.Scene(ctx, micro)
+    W, H = 96, 54
+    poses = [pose_matrix(0.1 * i, -0.2, -0.5 * i, 0.1 * i) for i in range(6)]
+    single = [sc.render(params(W, H, p, deferred=True), want=("rgba8",))["rgba8"] for p in poses]
+    bufs = [np.zeros((H, W, 4), np.uint8) for _ in poses]
+    for p, b in zip(poses, bufs):
+        fo = abi.FrameOut()
+        fo.rgba8 = b.ctypes.data
+        sc.submit(params(W, H, p, deferred=True), fo)
+    ctx.wait()
+    for a, b in zip(single, bufs):
+        assert np.array_equal(a, b)
+    sc.close()
+
+
+@pytest.fixture(scope="module")
+def proxy_small():
+    from vulkanrenderer_amd import scenes
+    return scenes.proxy_scene(detail=0.02, tex_size=64)
+
+
+@pytest.mark.parametrize("mode,kw", [("deferred", dict(deferred=True)), ("forward", dict(debug=1)), ("mip", dict(debug=2)),
+                                     ("deriv", dict(debug=4)), ("overdraw", dict(debug=5)), ("overshade", dict(debug=6)),
+                                     ("mosaic", dict(mosaic=True))])
+def test_proxy_scene_parity(ctx, proxy_small, mode, kw):
+    """A thinned SunTemple-proxy (all 48 materials, 3 alpha-masked, ~12k triangles) at 480x270 against the oracle."""
+    from oracle import oracle
+    from vulkanrenderer_amd import renderer
+    sc, osc = renderer.Scene(ctx, proxy_small), oracle.OracleScene(proxy_small)
+    for pose in (IDENTITY, pose_matrix(0.0, -2.0, -70.0, yaw=np.pi), pose_matrix(-5.0, -3.0, -6.0, yaw=0.9, pitch=-0.3)):
+        p = params(480, 270, pose, shadow=512, **kw)
+        ref, got = osc.render(p), sc.render(p)
+        for k in ("tri_id", "depth_bits", "stencil", "mip_level"):
+            assert np.array_equal(ref[k], got[k]), "%s %s: %d pixels differ" % (mode, k, int((ref[k] != got[k]).sum()))
+        if mode in ("forward", "mosaic"):
+            assert np.array_equal(ref["shadow_map"], got["shadow_map"])
+        d = np.abs(ref["rgba8"].astype(np.int32) - got["rgba8"].astype(np.int32))
+        assert d.max() <= 1, "%s colour off by %d at %d pixels" % (mode, int(d.max()), int((d > 1).sum()))
+        mse = np.mean(d.astype(np.float64) ** 2)
+        assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 50.0
+    sc.close(); osc.close()
+
+
+def test_properties_at_full_resolution(ctx):
+    """Size-independent properties at BASELINE.json's sizes (1920x1080 and 3840x2160) on a denser proxy scene."""
+    from vulkanrenderer_amd import renderer, scenes
+    from vulkanrenderer_amd.dist import band_rect
+    packed = scenes.proxy_scene(detail=0.25, tex_size=128)
+    sc = renderer.Scene(ctx, packed)
+    ntri = packed.triangle_count
+    pose = pose_matrix(0.0, -1.0, -20.0, yaw=0.2)
+    for (W, H) in ((1920, 1080), (3840, 2160)):
+        a = sc.render(params(W, H, pose, shadow=2048, deferred=True), want=("rgba8", "tri_id", "depth_bits"))
+        b = sc.render(params(W, H, pose, shadow=2048, deferred=True), want=("rgba8", "tri_id", "depth_bits"))
+        for k in a:
+            assert np.array_equal(a[k], b[k]), "not deterministic: " + k                      # idempotence
+        cov = a["tri_id"] != 0xFFFFFFFF
+        assert cov.mean() > 0.99 and a["tri_id"][cov].max() < ntri                              # inside a closed hall
+        z = a["depth_bits"].view(np.float32)
+        assert z.min() >= 0.0 and z.max() <= 1.0
+        # sort-first: 8 bands rendered one by one stitch to the single-pass frame, byte for byte
+        bands = [sc.render(params(W, H, pose, shadow=2048, deferred=True, rect=band_rect(r, 8, W, H)), want=("rgba8", "tri_id"))
+                 for r in range(8)]
+        assert np.array_equal(np.concatenate([x["rgba8"] for x in bands]), a["rgba8"])
+        assert np.array_equal(np.concatenate([x["tri_id"] for x in bands]), a["tri_id"])
+    W, H = 1920, 1080
+    od = sc.render(params(W, H, pose, debug=5), want=("stencil",))["stencil"]
+    os_ = sc.render(params(W, H, pose, debug=6), want=("stencil", "depth_bits"))
+    dv = sc.render(params(W, H, pose, debug=3), want=("depth_bits", "tri_id"))
+    assert np.all(os_["stencil"] <= od) and np.all((os_["stencil"] > 0) == (od > 0)) and od.max() > 3
+    assert np.array_equal(os_["depth_bits"], dv["depth_bits"])                                  # same visible surface
+    mo = sc.render(params(1920, 1080, pose, shadow=2048, mosaic=True), want=("rgba8",))["rgba8"]
+    blocks = mo.reshape(360, 3, 384, 5, 4)
+    assert np.all(blocks == blocks[:, :1, :, :1, :])                                            # 5x3 blocks are flat
+    sc.close()

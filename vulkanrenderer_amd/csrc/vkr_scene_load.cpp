@@ -12,6 +12,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -159,6 +160,22 @@ std::string decode_png(const std::vector<uint8_t>& file, std::vector<uint8_t>& r
 }
 
 } // namespace
+
+extern "C" int vkr_decode_png_file(const char* path, uint8_t** rgba8, uint32_t* width, uint32_t* height)
+{
+	if (!path || !rgba8 || !width || !height) return vkr_set_error_ext(VKR_E_INVALID, "vkr_decode_png_file: NULL argument");
+	*rgba8 = nullptr;
+	std::vector<uint8_t> png, out;
+	if (!read_file(path, png)) return vkr_set_error_ext(VKR_E_IO, "%s: Unable to load texture base image (cannot open)", path);
+	std::string err = decode_png(png, out, *width, *height);
+	if (!err.empty()) return vkr_set_error_ext(VKR_E_IO, "%s: Unable to load texture base image (%s)", path, err.c_str());
+	*rgba8 = (uint8_t*)malloc(out.size() ? out.size() : 1);
+	if (!*rgba8) return vkr_set_error_ext(VKR_E_NOMEM, "out of host memory");
+	memcpy(*rgba8, out.data(), out.size());
+	return VKR_OK;
+}
+
+extern "C" void vkr_free(void* p) { free(p); }
 
 extern "C" int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** out)
 {

@@ -19,7 +19,7 @@ EXPORTS = [
     "vkr_scene_destroy", "vkr_scene_stats", "vkr_scene_read_texture_level", "vkr_render", "vkr_wait",
     "vkr_update_scene_uniforms", "vkr_update_depth_mvp_uniforms", "vkr_default_lights", "vkr_make_uniforms",
     "vkr_profile_enable", "vkr_profile_reset", "vkr_stage_count", "vkr_stage_name", "vkr_profile_get",
-    "vkr_context_stream",
+    "vkr_context_stream", "vkr_decode_png_file", "vkr_free",
 ]
 
 
@@ -59,6 +59,9 @@ def lib():
         L.vkr_stage_name.restype = C.c_char_p
         L.vkr_stage_name.argtypes = [C.c_int]
         L.vkr_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.vkr_decode_png_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.vkr_free.argtypes = [C.c_void_p]
+        L.vkr_free.restype = None
         L.vkr_context_stream.restype = C.c_void_p
         L.vkr_context_stream.argtypes = [C.c_void_p]
         _lib = L
@@ -75,6 +78,16 @@ def make_uniforms(width, height, camera2world_c16, debug=1):
     u = abi.Uniforms()
     lib().vkr_make_uniforms(C.byref(u), width, height, (C.c_float * 16)(*[float(v) for v in camera2world_c16]), debug)
     return u
+
+
+def decode_png(path):
+    """uint8[h, w, 4], bottom row first, as the reference's texture loader sees it."""
+    p, w, h = C.POINTER(C.c_uint8)(), C.c_uint32(), C.c_uint32()
+    _check(lib().vkr_decode_png_file(path.encode(), C.byref(p), C.byref(w), C.byref(h)))
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib().vkr_free(p)
 
 
 SIDE = ("rgba8", "tri_id", "depth_bits", "mip_level", "stencil", "gbuf_normal", "gbuf_albedo", "shadow_map")
