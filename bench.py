@@ -41,6 +41,25 @@ def fly_pose(i, n=512):
     return [c, 0.0, -s, 0.0, 0.0, 1.0, 0.0, 0.0, s, 0.0, c, 0.0, 0.0, -1.0, tz, 1.0]
 
 
+def measured_traffic(width, height, kernel="k_deferred_light"):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*pmc_traffic*.json) taken at
+    this extent, or None.  PMC counters need their own rocprofv3 passes, so they cannot be collected inside this run."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
+        try:
+            with open(path) as f:
+                j = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if j.get("width") != width or j.get("height") != height:
+            continue
+        for name, k in j.get("kernels", {}).items():
+            if name.startswith(kernel) and "hbm_bytes_per_launch_corrected" in k:
+                best = (int(k["hbm_bytes_per_launch_corrected"]), os.path.basename(path))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,8 +164,10 @@ def main():
         avg_ms = light[0] / light[1]
         launch_pixels = W * rh
         achieved = LIGHT_BYTES_PER_PIXEL * launch_pixels / (avg_ms * 1e-3) / 1e9
+        traffic = measured_traffic(W, rh) if args.mode == "deferred" else None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "k_deferred_light",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic[0] if traffic else None,
+                    "traffic_source": ("profiles/" + traffic[1]) if traffic else None, "kernel": "k_deferred_light",
                     "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": LIGHT_BYTES_PER_PIXEL * launch_pixels}
 
     cpu = None
