@@ -38,19 +38,29 @@ __device__ __forceinline__ bool load_frag(const ResolveArgs& a, int px, int py, 
 	return true;
 }
 
+// colour-only (nothing integer depends on it): hardware reciprocal square root
 __device__ __forceinline__ void normalize3(float v[3])
 {
-	float inv = 1.0f / sqrtf(vkr_dot3(v[0], v[1], v[2], v[0], v[1], v[2]));
+	float inv = __builtin_amdgcn_rsqf(vkr_dot3(v[0], v[1], v[2], v[0], v[1], v[2]));
 	v[0] *= inv; v[1] *= inv; v[2] *= inv;
 }
 
-// normal = v2fTBN * normalize(texture(uNormalMap).rgb*2-1), TBN interpolated per vertex
+__device__ __forceinline__ void load_tbn(const ResolveArgs& a, uint32_t v, float m[9])
+{
+	const float4 c0 = a.sc.tbn[3 * (size_t)v + 0], c1 = a.sc.tbn[3 * (size_t)v + 1], c2 = a.sc.tbn[3 * (size_t)v + 2];
+	m[0] = c0.x; m[1] = c0.y; m[2] = c0.z; m[3] = c0.w;
+	m[4] = c1.x; m[5] = c1.y; m[6] = c1.z; m[7] = c1.w;
+	m[8] = c2.x;
+}
+
+// normal = v2fTBN * normalize(texture(uNormalMap).rgb*2-1), TBN interpolated
+// per vertex (default.vert:57-81 decoded once per vertex at scene creation)
 __device__ __forceinline__ void shading_normal(const ResolveArgs& a, const Frag& f, const float nm[4], float n[3])
 {
 	float m0[9], m1[9], m2[9];
-	vkr_decode_tbn(a.sc.tcomp[f.i0], m0);
-	vkr_decode_tbn(a.sc.tcomp[f.i1], m1);
-	vkr_decode_tbn(a.sc.tcomp[f.i2], m2);
+	load_tbn(a, f.i0, m0);
+	load_tbn(a, f.i1, m1);
+	load_tbn(a, f.i2, m2);
 	float m[9];
 #pragma unroll
 	for (int i = 0; i < 9; i++) m[i] = vkr_interp(f.b, m0[i], m1[i], m2[i]);
@@ -58,6 +68,33 @@ __device__ __forceinline__ void shading_normal(const ResolveArgs& a, const Frag&
 	normalize3(t);
 #pragma unroll
 	for (int r = 0; r < 3; r++) n[r] = fmaf(m[6 + r], t[2], fmaf(m[3 + r], t[1], m[0 + r] * t[0]));
+}
+
+// The four material fetches of gBufWrite.frag / default.frag: normal map rgb,
+// base colour rgb, metalness r, roughness r.  The footprint (level, weights,
+// texel indices) is rebuilt only when a texture's size differs from the
+// previous one's.
+struct MatSample { float nm[4], alb[4], metal, rough; };
+
+__device__ __forceinline__ void sample_material(const ResolveArgs& a, const Frag& f, const float* dec, MatSample& o)
+{
+	const MatInfo& mi = a.sc.mat[f.mat];
+	TexTaps tp;
+	float t[4];
+	const TexInfo& tn = a.sc.tex[mi.tex[4]];
+	vkr_make_taps(tn, f.uv[0], f.uv[1], f.d, tp);
+	vkr_fetch<7>(a.sc, tn, tp, dec, o.nm);
+	const TexInfo& ta = a.sc.tex[mi.tex[0]];
+	if (!vkr_same_dims(ta, tp)) vkr_make_taps(ta, f.uv[0], f.uv[1], f.d, tp);
+	vkr_fetch<7>(a.sc, ta, tp, dec, o.alb);
+	const TexInfo& tm = a.sc.tex[mi.tex[1]];
+	if (!vkr_same_dims(tm, tp)) vkr_make_taps(tm, f.uv[0], f.uv[1], f.d, tp);
+	vkr_fetch<1>(a.sc, tm, tp, dec, t);
+	o.metal = t[0];
+	const TexInfo& tr = a.sc.tex[mi.tex[2]];
+	if (!vkr_same_dims(tr, tp)) vkr_make_taps(tr, f.uv[0], f.uv[1], f.d, tp);
+	vkr_fetch<1>(a.sc, tr, tp, dec, t);
+	o.rough = t[0];
 }
 
 __device__ __forceinline__ void decode_key(unsigned long long key, float& depth, uint32_t& prim)
@@ -69,6 +106,9 @@ __device__ __forceinline__ void decode_key(unsigned long long key, float& depth,
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resolve_gbuf(ResolveArgs a)
 {
+	__shared__ float sDec[256];
+	sDec[threadIdx.x] = a.sc.srgbDecode[threadIdx.x];
+	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
 	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
 	if (x >= rw || y >= rh) return;
@@ -82,17 +122,14 @@ __global__ __launch_bounds__(256) void k_resolve_gbuf(ResolveArgs a)
 	uint2 gn = make_uint2(0x2E662E66u, 0x2E662E66u), ga = gn;
 	Frag f;
 	if (prim != VKR_NO_PRIM && load_frag<false>(a, px, py, prim, f)) {
-		const MatInfo& mi = a.sc.mat[f.mat];
-		float nm[4], alb[4], me[4], ro[4], N[3];
-		vkr_trilinear(a.sc, a.sc.tex[mi.tex[4]], f.uv[0], f.uv[1], f.d, nm);
-		vkr_trilinear(a.sc, a.sc.tex[mi.tex[0]], f.uv[0], f.uv[1], f.d, alb);
-		vkr_trilinear(a.sc, a.sc.tex[mi.tex[1]], f.uv[0], f.uv[1], f.d, me);
-		vkr_trilinear(a.sc, a.sc.tex[mi.tex[2]], f.uv[0], f.uv[1], f.d, ro);
-		shading_normal(a, f, nm, N);
-		gn.x = (uint32_t)vkr_f2h(N[0]) | ((uint32_t)vkr_f2h(N[1]) << 16);
-		gn.y = (uint32_t)vkr_f2h(N[2]) | ((uint32_t)vkr_f2h(me[0]) << 16);
-		ga.x = (uint32_t)vkr_f2h(alb[0]) | ((uint32_t)vkr_f2h(alb[1]) << 16);
-		ga.y = (uint32_t)vkr_f2h(alb[2]) | ((uint32_t)vkr_f2h(ro[0]) << 16);
+		MatSample ms;
+		float N[3];
+		sample_material(a, f, sDec, ms);
+		shading_normal(a, f, ms.nm, N);
+		gn.x = vkr_f2h_hw(N[0]) | (vkr_f2h_hw(N[1]) << 16);
+		gn.y = vkr_f2h_hw(N[2]) | (vkr_f2h_hw(ms.metal) << 16);
+		ga.x = vkr_f2h_hw(ms.alb[0]) | (vkr_f2h_hw(ms.alb[1]) << 16);
+		ga.y = vkr_f2h_hw(ms.alb[2]) | (vkr_f2h_hw(ms.rough) << 16);
 	}
 	a.gN[p] = gn;
 	a.gA[p] = ga;
@@ -149,6 +186,9 @@ __device__ __forceinline__ float shadow_lookup(const float* sm, int S, float u, 
 
 __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 {
+	__shared__ float sDec[256];
+	sDec[threadIdx.x] = a.sc.srgbDecode[threadIdx.x];
+	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
 	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
 	if (x >= rw || y >= rh) return;
@@ -162,13 +202,11 @@ __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 	uint32_t colour = vkr_pack_colour(a.sc.srgbThresh, 0.1f, 0.1f, 0.1f, 1.0f);
 	Frag f;
 	if (prim != VKR_NO_PRIM && load_frag<false>(a, px, py, prim, f)) {
-		const MatInfo& mi = a.sc.mat[f.mat];
-		float nm[4], alb[4], me[4], ro[4], N[3], P[3];
-		vkr_trilinear(a.sc, a.sc.tex[mi.tex[4]], f.uv[0], f.uv[1], f.d, nm);
-		vkr_trilinear(a.sc, a.sc.tex[mi.tex[0]], f.uv[0], f.uv[1], f.d, alb);
-		vkr_trilinear(a.sc, a.sc.tex[mi.tex[1]], f.uv[0], f.uv[1], f.d, me);
-		vkr_trilinear(a.sc, a.sc.tex[mi.tex[2]], f.uv[0], f.uv[1], f.d, ro);
-		shading_normal(a, f, nm, N);
+		MatSample ms;
+		float N[3], P[3];
+		sample_material(a, f, sDec, ms);
+		const float* alb = ms.alb;
+		shading_normal(a, f, ms.nm, N);
 #pragma unroll
 		for (int i = 0; i < 3; i++)
 			P[i] = vkr_interp(f.b, a.sc.pos[3 * (size_t)f.i0 + i], a.sc.pos[3 * (size_t)f.i1 + i], a.sc.pos[3 * (size_t)f.i2 + i]);
@@ -179,7 +217,7 @@ __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 		normalize3(L);
 		normalize3(Vv);
 		float br[3];
-		brdf_forward(L, Vv, N, alb, me[0], ro[0], br);
+		brdf_forward(L, Vv, N, alb, ms.metal, ms.rough, br);
 		float ndl = fmaxf(vkr_dot3(N[0], N[1], N[2], L[0], L[1], L[2]), 0.0001f);
 		float att = 1.0f / dist2;
 		float4 ls = vkr_xform(a.lightMat, P[0], P[1], P[2]);

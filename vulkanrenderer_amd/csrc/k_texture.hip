@@ -57,3 +57,25 @@ void vkr_launch_mip_level(hipStream_t s, uint32_t* texels, uint32_t srcOff, uint
 	dim3 g((dw + 15) / 16, (dh + 15) / 16);
 	hipLaunchKernelGGL(k_mip_level, g, dim3(256), 0, s, texels, srcOff, sw, sh, dstOff, dw, dh, srgb, srgbDecode, srgbThresh);
 }
+
+// ---------------------------------------------------------------------------
+// TBN matrices of default.vert:57-81, decoded once per vertex at scene
+// creation instead of three times per shaded pixel: 3 float4 per vertex
+// holding the 9 column-major entries.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tbn_table(const uint32_t* __restrict__ tcomp, float4* __restrict__ out, uint32_t n)
+{
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= n) return;
+	float m[9];
+	vkr_decode_tbn(tcomp[v], m);
+	out[3 * (size_t)v + 0] = make_float4(m[0], m[1], m[2], m[3]);
+	out[3 * (size_t)v + 1] = make_float4(m[4], m[5], m[6], m[7]);
+	out[3 * (size_t)v + 2] = make_float4(m[8], 0.0f, 0.0f, 0.0f);
+}
+
+void vkr_launch_tbn_table(hipStream_t s, const uint32_t* tcomp, float4* out, uint32_t nVert)
+{
+	if (!nVert) return;
+	hipLaunchKernelGGL(k_tbn_table, dim3((nVert + 255) / 256), dim3(256), 0, s, tcomp, out, nVert);
+}

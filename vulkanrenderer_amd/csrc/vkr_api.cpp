@@ -117,7 +117,7 @@ struct HostTex { uint32_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS], off[VKR_MAX_LEVE
 
 struct vkr_scene {
 	vkr_context* ctx = nullptr;
-	DevBuf pos, uv, tcomp, tri, triMat, orderB, tex, mat, texels;
+	DevBuf pos, uv, tcomp, tbn, tri, triMat, orderB, tex, mat, texels;
 	SceneDev dev;
 	std::vector<HostTex> htex;
 	uint64_t nTri = 0, nVert = 0, texelCount = 0;
@@ -412,7 +412,7 @@ extern "C" void vkr_scene_destroy(vkr_scene* s)
 {
 	if (!s) return;
 	if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
-	DevBuf* bufs[] = { &s->pos, &s->uv, &s->tcomp, &s->tri, &s->triMat, &s->orderB, &s->tex, &s->mat, &s->texels };
+	DevBuf* bufs[] = { &s->pos, &s->uv, &s->tcomp, &s->tbn, &s->tri, &s->triMat, &s->orderB, &s->tex, &s->mat, &s->texels };
 	for (DevBuf* b : bufs) b->release();
 	delete s;
 }
@@ -505,6 +505,8 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 	if ((rc = upload(s->pos, pos.data(), pos.size() * 4))) return fail(rc);
 	if ((rc = upload(s->uv, uv.data(), uv.size() * 4))) return fail(rc);
 	if ((rc = upload(s->tcomp, tcomp.data(), tcomp.size() * 4))) return fail(rc);
+	if ((rc = s->tbn.ensure(nVert ? nVert * 3 * sizeof(float4) : 16))) return fail(rc);
+	vkr_launch_tbn_table(c->stream, s->tcomp.as<uint32_t>(), s->tbn.as<float4>(), (uint32_t)nVert);
 	if ((rc = upload(s->tri, tri.data(), tri.size() * 4))) return fail(rc);
 	if ((rc = upload(s->triMat, triMat.data(), triMat.size() * 4))) return fail(rc);
 	if ((rc = upload(s->orderB, orderB.data(), orderB.size() * 4))) return fail(rc);
@@ -574,7 +576,7 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 		if (e != hipSuccess) return fail(set_error(VKR_E_DEVICE, "mip generation: %s", hipGetErrorString(e)));
 	}
 	SceneDev& dv = s->dev;
-	dv.pos = s->pos.as<float>(); dv.uv = s->uv.as<float>(); dv.tcomp = s->tcomp.as<uint32_t>();
+	dv.pos = s->pos.as<float>(); dv.uv = s->uv.as<float>(); dv.tcomp = s->tcomp.as<uint32_t>(); dv.tbn = s->tbn.as<float4>();
 	dv.tri = s->tri.as<uint32_t>(); dv.triMat = s->triMat.as<uint32_t>(); dv.orderB = s->orderB.as<uint32_t>();
 	dv.tex = s->tex.as<TexInfo>(); dv.mat = s->mat.as<MatInfo>(); dv.texels = s->texels.as<uint32_t>();
 	dv.srgbDecode = c->dDecode; dv.srgbThresh = c->dThresh;

@@ -54,6 +54,7 @@ struct SceneDev {
 	const float* pos;        // 3 per vertex
 	const float* uv;         // 2 per vertex
 	const uint32_t* tcomp;   // packed TBN quaternion per vertex
+	const float4* tbn;       // decoded TBN matrix per vertex: 3 float4 (9 entries, column-major, + 3 unused)
 	const uint32_t* tri;     // 3 global vertex indices per triangle, submission order A
 	const uint32_t* triMat;  // material per triangle (order A)
 	const uint32_t* orderB;  // file-order rank of triangle t (order A index -> order B index)
@@ -115,6 +116,35 @@ __device__ __forceinline__ float vkr_h2f(uint16_t h)
 	}
 	if (e == 31) return u2f(sign | 0x7f800000u | (m << 13));
 	return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+// float -> half with the conversion instruction (round to nearest even, half
+// denormals kept): the same value as vkr_f2h for every input; NaNs are mapped
+// to the one quiet NaN vkr_f2h produces.
+__device__ __forceinline__ uint32_t vkr_f2h_hw(float f)
+{
+	uint32_t h = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f);
+	if (f != f) h = ((f2u(f) >> 16) & 0x8000u) | 0x7e00u;
+	return h;
+}
+
+// (float)k / 255.0f for k in [0,255] and (float)k / 1023.0f for k in [0,1023]
+// without the division sequence: one Newton step on k * (1/n) is the
+// correctly rounded quotient for every such k (checked exhaustively on the
+// host), so these are bit-identical to the divisions they replace.
+__device__ __forceinline__ float vkr_unorm8(uint32_t k)
+{
+	const float R = 1.0f / 255.0f;
+	const float kf = (float)k;
+	const float q = kf * R;
+	return fmaf(fmaf(-q, 255.0f, kf), R, q);
+}
+__device__ __forceinline__ float vkr_unorm10(uint32_t k)
+{
+	const float R = 1.0f / 1023.0f;
+	const float kf = (float)k;
+	const float q = kf * R;
+	return fmaf(fmaf(-q, 1023.0f, kf), R, q);
 }
 
 __device__ __forceinline__ float vkr_clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
@@ -287,96 +317,130 @@ __device__ __forceinline__ float vkr_rho2(const TexInfo& t, const float d[4])
 
 __device__ __forceinline__ int vkr_wrap(int i, int n)
 {
+	if ((n & (n - 1)) == 0) return i & (n - 1); // power of two: two's complement AND is the non-negative remainder
 	int r = i % n;
 	return r < 0 ? r + n : r;
 }
 
-__device__ __forceinline__ void vkr_texel(const SceneDev& sc, const TexInfo& t, int level, int x, int y, float out[4])
-{
-	uint32_t p = sc.texels[t.offset[level] + (uint32_t)y * t.w[level] + (uint32_t)x];
-	if (t.srgb) {
-		out[0] = sc.srgbDecode[p & 0xffu];
-		out[1] = sc.srgbDecode[(p >> 8) & 0xffu];
-		out[2] = sc.srgbDecode[(p >> 16) & 0xffu];
-	} else {
-		out[0] = (float)(p & 0xffu) / 255.0f;
-		out[1] = (float)((p >> 8) & 0xffu) / 255.0f;
-		out[2] = (float)((p >> 16) & 0xffu) / 255.0f;
-	}
-	out[3] = (float)(p >> 24) / 255.0f;
-}
+// Bilinear footprint of one mip level: texel indices inside the level and the
+// two weights.  REPEAT addressing; x1 = x0 + 1 wrapped.
+struct LevelTaps {
+	uint32_t i00, i10, i01, i11;
+	float fx, fy;
+};
 
-__device__ __forceinline__ void vkr_bilinear(const SceneDev& sc, const TexInfo& t, int level, float u, float v, float out[4])
+__device__ __forceinline__ void vkr_level_taps(int w, int h, float u, float v, LevelTaps& o)
 {
-	int w = t.w[level], h = t.h[level];
 	float x = u * (float)w - 0.5f;
 	float y = v * (float)h - 0.5f;
 	if (!(fabsf(x) < 1.0e9f)) x = 0.0f;
 	if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
 	float x0f = floorf(x), y0f = floorf(y);
-	float fx = x - x0f, fy = y - y0f;
-	int x0 = vkr_wrap((int)x0f, w), x1 = vkr_wrap((int)x0f + 1, w);
-	int y0 = vkr_wrap((int)y0f, h), y1 = vkr_wrap((int)y0f + 1, h);
-	float t00[4], t10[4], t01[4], t11[4];
-	vkr_texel(sc, t, level, x0, y0, t00);
-	vkr_texel(sc, t, level, x1, y0, t10);
-	vkr_texel(sc, t, level, x0, y1, t01);
-	vkr_texel(sc, t, level, x1, y1, t11);
-#pragma unroll
-	for (int c = 0; c < 4; c++) out[c] = vkr_lerp(vkr_lerp(t00[c], t10[c], fx), vkr_lerp(t01[c], t11[c], fx), fy);
+	o.fx = x - x0f; o.fy = y - y0f;
+	int x0 = vkr_wrap((int)x0f, w), y0 = vkr_wrap((int)y0f, h);
+	int x1 = x0 + 1, y1 = y0 + 1;
+	if (x1 == w) x1 = 0;
+	if (y1 == h) y1 = 0;
+	o.i00 = (uint32_t)(y0 * w + x0); o.i10 = (uint32_t)(y0 * w + x1);
+	o.i01 = (uint32_t)(y1 * w + x0); o.i11 = (uint32_t)(y1 * w + x1);
 }
 
+// Everything about a trilinear fetch that depends only on the texture's
+// dimensions: level, fraction and the footprint on each of the two levels.
+// Textures of one material usually share their size, so one TexTaps serves
+// several fetches (vkr_same_dims).
+struct TexTaps {
+	uint32_t w0, h0;
+	int levels;
+	int lv;      // lower level
+	float fr;    // weight of level lv+1; 0 = single level
+	LevelTaps t0, t1;
+};
+
+__device__ __forceinline__ bool vkr_same_dims(const TexInfo& t, const TexTaps& tp)
+{
+	return t.w[0] == tp.w0 && t.h[0] == tp.h0 && t.levels == tp.levels;
+}
+
+__device__ __forceinline__ void vkr_make_taps(const TexInfo& t, float u, float v, const float d[4], TexTaps& tp)
+{
+	tp.w0 = t.w[0]; tp.h0 = t.h[0]; tp.levels = t.levels;
+	vkr_lod_split(vkr_rho2(t, d), t.levels - 1, tp.lv, tp.fr);
+	// level sizes halve, rounding down, not below 1 (utils/vkimage.cpp:165-197)
+	int w = (int)(tp.w0 >> tp.lv), h = (int)(tp.h0 >> tp.lv);
+	if (w < 1) w = 1;
+	if (h < 1) h = 1;
+	vkr_level_taps(w, h, u, v, tp.t0);
+	if (tp.fr != 0.0f) {
+		int w1 = (int)(tp.w0 >> (tp.lv + 1)), h1 = (int)(tp.h0 >> (tp.lv + 1));
+		if (w1 < 1) w1 = 1;
+		if (h1 < 1) h1 = 1;
+		vkr_level_taps(w1, h1, u, v, tp.t1);
+	}
+}
+
+// channel c (0..2 colour, 3 alpha) of a packed texel; dec = 256-entry sRGB decode table or nullptr for UNORM
+__device__ __forceinline__ float vkr_channel(uint32_t p, int c, const float* dec)
+{
+	const uint32_t k = (p >> (8 * c)) & 0xffu;
+	return (dec && c < 3) ? dec[k] : vkr_unorm8(k);
+}
+
+// bilinear fetch of the channels in MASK on one level
+template <int MASK>
+__device__ __forceinline__ void vkr_bilinear_taps(const uint32_t* __restrict__ base, const LevelTaps& lt, const float* dec, float out[4])
+{
+	const uint32_t p00 = base[lt.i00], p10 = base[lt.i10], p01 = base[lt.i01], p11 = base[lt.i11];
+#pragma unroll
+	for (int c = 0; c < 4; c++)
+		if (MASK & (1 << c))
+			out[c] = vkr_lerp(vkr_lerp(vkr_channel(p00, c, dec), vkr_channel(p10, c, dec), lt.fx),
+			                  vkr_lerp(vkr_channel(p01, c, dec), vkr_channel(p11, c, dec), lt.fx), lt.fy);
+}
+
+// texture(sampler, uv) for the channels in MASK with a prepared footprint.
+// srgbDecode: the 256-entry table (global or LDS) used when the texture is sRGB.
+template <int MASK>
+__device__ __forceinline__ void vkr_fetch(const SceneDev& sc, const TexInfo& t, const TexTaps& tp, const float* srgbDecode, float out[4])
+{
+	const float* dec = t.srgb ? srgbDecode : nullptr;
+	const uint32_t* b0 = sc.texels + t.offset[tp.lv];
+	if (tp.fr == 0.0f) { vkr_bilinear_taps<MASK>(b0, tp.t0, dec, out); return; }
+	const uint32_t* b1 = sc.texels + t.offset[tp.lv + 1];
+	float a[4], b[4];
+	vkr_bilinear_taps<MASK>(b0, tp.t0, dec, a);
+	vkr_bilinear_taps<MASK>(b1, tp.t1, dec, b);
+#pragma unroll
+	for (int c = 0; c < 4; c++)
+		if (MASK & (1 << c)) out[c] = vkr_lerp(a[c], b[c], tp.fr);
+}
+
+// one-off trilinear fetch (all four channels)
 __device__ __forceinline__ void vkr_trilinear(const SceneDev& sc, const TexInfo& t, float u, float v, const float d[4],
                                               float out[4])
 {
-	int lv; float fr;
-	vkr_lod_split(vkr_rho2(t, d), t.levels - 1, lv, fr);
-	if (fr == 0.0f) { vkr_bilinear(sc, t, lv, u, v, out); return; }
-	float a[4], b[4];
-	vkr_bilinear(sc, t, lv, u, v, a);
-	vkr_bilinear(sc, t, lv + 1, u, v, b);
-#pragma unroll
-	for (int c = 0; c < 4; c++) out[c] = vkr_lerp(a[c], b[c], fr);
+	TexTaps tp;
+	vkr_make_taps(t, u, v, d, tp);
+	vkr_fetch<15>(sc, t, tp, sc.srgbDecode, out);
 }
 
-// Alpha channel only (the alpha test needs nothing else): same arithmetic as
-// the .a component of vkr_bilinear / vkr_trilinear.
-__device__ __forceinline__ float vkr_bilinear_alpha(const SceneDev& sc, const TexInfo& t, int level, float u, float v)
-{
-	int w = t.w[level], h = t.h[level];
-	float x = u * (float)w - 0.5f;
-	float y = v * (float)h - 0.5f;
-	if (!(fabsf(x) < 1.0e9f)) x = 0.0f;
-	if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
-	float x0f = floorf(x), y0f = floorf(y);
-	float fx = x - x0f, fy = y - y0f;
-	int x0 = vkr_wrap((int)x0f, w), x1 = vkr_wrap((int)x0f + 1, w);
-	int y0 = vkr_wrap((int)y0f, h), y1 = vkr_wrap((int)y0f + 1, h);
-	const uint32_t* base = sc.texels + t.offset[level];
-	float t00 = (float)(base[(uint32_t)y0 * w + (uint32_t)x0] >> 24) / 255.0f;
-	float t10 = (float)(base[(uint32_t)y0 * w + (uint32_t)x1] >> 24) / 255.0f;
-	float t01 = (float)(base[(uint32_t)y1 * w + (uint32_t)x0] >> 24) / 255.0f;
-	float t11 = (float)(base[(uint32_t)y1 * w + (uint32_t)x1] >> 24) / 255.0f;
-	return vkr_lerp(vkr_lerp(t00, t10, fx), vkr_lerp(t01, t11, fx), fy);
-}
-
+// alpha channel only (the alpha test needs nothing else)
 __device__ __forceinline__ float vkr_trilinear_alpha(const SceneDev& sc, const TexInfo& t, float u, float v, const float d[4])
 {
-	int lv; float fr;
-	vkr_lod_split(vkr_rho2(t, d), t.levels - 1, lv, fr);
-	if (fr == 0.0f) return vkr_bilinear_alpha(sc, t, lv, u, v);
-	float a = vkr_bilinear_alpha(sc, t, lv, u, v);
-	float b = vkr_bilinear_alpha(sc, t, lv + 1, u, v);
-	return vkr_lerp(a, b, fr);
+	TexTaps tp;
+	float out[4];
+	vkr_make_taps(t, u, v, d, tp);
+	vkr_fetch<8>(sc, t, tp, nullptr, out);
+	return out[3];
 }
 
 // TBN decode (default.vert:57-81): GLSL mat3 column-major m[c*3+r]
 __device__ __forceinline__ void vkr_decode_tbn(uint32_t packed, float m[9])
 {
 	const float SQRT2 = 1.41421354f, INV_SQRT2 = 0.707106769f;
-	float r = (float)((packed >> 20) & 0x3ffu) / 1023.0f;
-	float g = (float)((packed >> 10) & 0x3ffu) / 1023.0f;
-	float b = (float)(packed & 0x3ffu) / 1023.0f;
+	float r = vkr_unorm10((packed >> 20) & 0x3ffu);
+	float g = vkr_unorm10((packed >> 10) & 0x3ffu);
+	float b = vkr_unorm10(packed & 0x3ffu);
 	int maxIndex = (int)(packed >> 30);
 	float s0 = r * SQRT2 - INV_SQRT2, s1 = g * SQRT2 - INV_SQRT2, s2 = b * SQRT2 - INV_SQRT2;
 	float dd = fmaf(s2, s2, fmaf(s1, s1, s0 * s0));
