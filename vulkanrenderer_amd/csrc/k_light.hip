@@ -7,13 +7,28 @@
 
 // ---------------------------------------------------------------------------
 // deferredShading.frag:92-119.  One thread per pixel; reads the two RGBA16F
-// G-buffer attachments and D32 depth (20 B), writes RGBA8 (4 B).  Everything
-// that does not depend on the light is hoisted out of the 21-iteration loop;
-// each light costs two rsqrt, four rcp and one exp2.
+// G-buffer attachments and D32 depth (20 B), writes RGBA8 (4 B).
+//
+// The kernel is bound by vector-ALU issue, not by memory, so the shader's
+// arithmetic is reorganised to the fewest instructions per (pixel, light):
+//  * With H = (V+L)/|V+L| and unit V, L:  |V+L|^2 = 2(1+V.L),
+//    N.H = (N.V+N.L)/|V+L|,  V.H = (1+V.L)/|V+L| = 1/(2 invh) with
+//    invh = rsq(2(1+V.L)); H itself is never formed and 1/(V.H) = 2 invh.
+//  * D's exponent (nh^2-1)/(r^2 nh^2) = (1 - 1/nh^2)/r^2: one rcp, one fma.
+//  * D's denominator and the BRDF denominator share one reciprocal.
+//  * The Fresnel/diffuse/specular mix is linear in three per-light scalars:
+//      brdf_c = kd_c (1-f0_c) (1-x^5) + f0_c spec + (1-f0_c) spec x^5,  x = 1 - V.H,
+//    so when every light has the same colour (the reference's 21 braziers,
+//    main/main.cpp:1350-1352) the per-channel work leaves the loop entirely:
+//    the loop accumulates S1 = sum t(1-x^5), S2 = sum t spec, S3 = sum t spec x^5
+//    (t = N.L/d^2) and the channels are combined once at the end.
+//  * max(.,0) of quantities bounded by 1 uses the free clamp modifier.
+// Per light: 42 plain VALU instructions and 5 transcendentals (2 rsq, 2 rcp, 1 exp2).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float sat(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 
 __device__ __forceinline__ float h2f_lo(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)); }
 __device__ __forceinline__ float h2f_hi(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); }
@@ -35,6 +50,7 @@ __device__ __forceinline__ uint32_t srgb_encode_fast(const float* T, float x)
 	return (uint32_t)code;
 }
 
+template <bool SAMECOL>
 __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 {
 	__shared__ float sT[257];
@@ -79,57 +95,65 @@ __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 	// light-independent terms
 	const float ndv = Nx * Vx + Ny * Vy + Nz * Vz;
 	const float ndvp = fmaxf(ndv, 0.0f);
-	const float ndvp4 = 4.0f * ndvp;
 	const float pir2 = PI * r2;
+	const float cexp = LOG2E / fmaxf(r2, 1.0e-30f); // exponent of D is cexp * (1 - 1/nh^2)
+	const float V2x = Vx + Vx, V2y = Vy + Vy, V2z = Vz + Vz;
 	const float om = 1.0f - metal;
-	float f0[3], omf0[3], kd[3];
+	float f0[3], omf0[3], kdo[3];
 #pragma unroll
 	for (int c = 0; c < 3; c++) {
 		f0[c] = om * 0.04f + metal * alb[c];
 		omf0[c] = 1.0f - f0[c];
-		kd[c] = (alb[c] / PI) * om;
+		kdo[c] = (alb[c] / PI) * om * omf0[c];
 	}
-	// With H = (V+L)/|V+L| and |V| = |L| = 1:  |V+L|^2 = 2(1 + V.L),
-	// N.H = (N.V + N.L)/|V+L|,  V.H = (1 + V.L)/|V+L|.
-	float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	float S0 = 0.0f;                          // sum 1/d^2 (ambient)
+	float S1[3] = { 0, 0, 0 }, S2[3] = { 0, 0, 0 }, S3[3] = { 0, 0, 0 }; // SAMECOL: only [0] is used
 #pragma unroll 3
 	for (int i = 0; i < VKR_NUM_LIGHTS_K; i++) {
 		const float Lx = a.lightPos[i][0] - Px, Ly = a.lightPos[i][1] - Py, Lz = a.lightPos[i][2] - Pz;
 		const float d2 = Lx * Lx + Ly * Ly + Lz * Lz;
 		const float invd = fast_rsq(d2);
 		const float invd2 = invd * invd;
-		const float ndl = (Nx * Lx + Ny * Ly + Nz * Lz) * invd;
-		const float opv = 1.0f + (Vx * Lx + Vy * Ly + Vz * Lz) * invd; // 1 + V.L
-		const float invh = fast_rsq(opv + opv);
-		const float ndhp = fmaxf((ndv + ndl) * invh, 0.0f);
-		const float ndlp = fmaxf(ndl, 0.0f);
-		const float vdh = opv * invh;
-		// D = exp((nh^2-1)/(r^2 nh^2)) / (0.001 + pi r^2 nh^4)
-		const float nh2 = ndhp * ndhp, nh4 = nh2 * nh2;
-		const float ex = fast_exp2((nh2 - 1.0f) * LOG2E * fast_rcp(r2 * nh2));
-		// one reciprocal for D's denominator and the BRDF denominator (both >= 0.001)
-		const float rden = fast_rcp((0.001f + pir2 * nh4) * (0.001f + ndvp4 * ndlp));
-		// F = f0 + (1-f0) (1 - v.h)^5
-		const float xx = 1.0f - vdh;
+		const float nl = Nx * Lx + Ny * Ly + Nz * Lz;
+		const float ndl = nl * invd;
+		const float ndlp = sat(nl * invd);                       // max(N.L, 0); N.L <= 1
+		const float opv2 = (V2x * Lx + V2y * Ly + V2z * Lz) * invd + 2.0f; // 2 (1 + V.L) = |V+L|^2
+		const float invh = fast_rsq(opv2);
+		const float xx = 1.0f - 0.5f * (opv2 * invh);           // 1 - V.H
+		const float ndh = sat((ndv + ndl) * invh);               // max(N.H, 0)
+		const float nh2 = ndh * ndh, nh4 = nh2 * nh2;
+		const float ex = fast_exp2(cexp - cexp * fast_rcp(nh2));
+		// D's denominator times a quarter of the BRDF denominator, one reciprocal for both
+		const float rden = fast_rcp((0.001f + pir2 * nh4) * (0.00025f + ndvp * ndlp));
 		const float x2 = xx * xx, x5 = x2 * x2 * xx;
-		// G = min(1, 2 n.h n.v / v.h, 2 n.h n.l / v.h)
-		const float g0 = (ndhp + ndhp) * fast_rcp(vdh);
-		const float G = fminf(1.0f, fminf(g0 * ndvp, g0 * ndlp));
-		const float spec = ex * G * rden;
-		const float t = 10.0f * ndlp * invd2;
+		// G/4 = min(1/4, n.h min(n.v, n.l) / (2 v.h)),  1/(2 v.h) = invh
+		const float Gq = fminf((ndh * invh) * fminf(ndvp, ndlp), 0.25f);
+		const float spec = ex * Gq * rden;                       // D G / (0.001 + 4 n.v n.l)
+		const float t = ndlp * invd2;
+		const float ts = t * spec;
+		const float ty = t - t * x5;                             // t (1 - x^5)
+		const float tsx = ts * x5;
+		S0 += invd2;
+		if (SAMECOL) {
+			S1[0] += ty; S2[0] += ts; S3[0] += tsx;
+		} else {
 #pragma unroll
-		for (int c = 0; c < 3; c++) {
-			const float F = f0[c] + omf0[c] * x5;
-			const float br = kd[c] + F * (spec - kd[c]); // kd (1-F) + spec F
-			acc[c] += br * (a.lightCol[i][c] * t);
+			for (int c = 0; c < 3; c++) {
+				S1[c] += a.lightCol[i][c] * ty; S2[c] += a.lightCol[i][c] * ts; S3[c] += a.lightCol[i][c] * tsx;
+			}
 		}
-		acc[3] += invd2;
 	}
-	// ambient 0.03*albedo is added per light and attenuated with it (deferredShading.frag:108,115)
+	// colour_c = 10 col_c (kd_c(1-f0_c) S1 + f0_c S2 + (1-f0_c) S3) + 0.03 albedo_c S0: the ambient term is
+	// added per light and attenuated with it (deferredShading.frag:108,115)
+	float acc[3];
 #pragma unroll
-	for (int c = 0; c < 3; c++) acc[c] += 0.03f * alb[c] * acc[3];
+	for (int c = 0; c < 3; c++) {
+		const float lit = SAMECOL ? a.lightCol[0][c] * (kdo[c] * S1[0] + f0[c] * S2[0] + omf0[c] * S3[0])
+		                          : (kdo[c] * S1[c] + f0[c] * S2[c] + omf0[c] * S3[c]);
+		acc[c] = 10.0f * lit + 0.03f * alb[c] * S0;
+	}
 	a.colour[p] = srgb_encode_fast(sT, acc[0]) | (srgb_encode_fast(sT, acc[1]) << 8) | (srgb_encode_fast(sT, acc[2]) << 16) |
-	              (vkr_unorm_encode(vkr_clamp01(acc[3])) << 24);
+	              (vkr_unorm_encode(vkr_clamp01(S0)) << 24);
 }
 
 // overVisRead.frag:7-13: oColor = (0,0.3,0,0.1) + vec4(vec3(stencil/25), 0)
@@ -197,7 +221,12 @@ void vkr_launch_deferred_light(hipStream_t s, const LightArgs& a)
 {
 	const uint32_t n = (a.view.x1 - a.view.x0) * (a.view.y1 - a.view.y0);
 	if (!n) return;
-	hipLaunchKernelGGL(k_deferred_light, dim3((n + 255) / 256), dim3(256), 0, s, a);
+	// every light the same colour (the reference's braziers): the per-channel work leaves the light loop
+	bool same = true;
+	for (int i = 1; i < VKR_NUM_LIGHTS_K; i++)
+		for (int c = 0; c < 3; c++) same = same && a.lightCol[i][c] == a.lightCol[0][c];
+	if (same) hipLaunchKernelGGL(k_deferred_light<true>, dim3((n + 255) / 256), dim3(256), 0, s, a);
+	else hipLaunchKernelGGL(k_deferred_light<false>, dim3((n + 255) / 256), dim3(256), 0, s, a);
 }
 
 void vkr_launch_overvis_colour(hipStream_t s, const uint8_t* stencil, uint32_t* colour, const float* srgbThresh, uint32_t n)
