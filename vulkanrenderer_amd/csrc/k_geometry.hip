@@ -19,6 +19,43 @@ __global__ __launch_bounds__(256) void k_xform(const float* __restrict__ pos, fl
 }
 
 // ---------------------------------------------------------------------------
+// Wave-aggregated "counter[tile] += 1" for the lanes with valid set: lanes of
+// the wave that target the same tile are grouped (no memory traffic while
+// grouping), each group's first lane issues one atomic for the whole group,
+// and every lane gets old value + its rank inside the group.  Distant geometry
+// puts thousands of one-tile triangles into the same few tiles; without the
+// grouping those same-address atomics serialise in L2.  After MAXG groups the
+// remaining lanes fall back to one atomic each.
+// ---------------------------------------------------------------------------
+template <bool RETURNS>
+__device__ __forceinline__ uint32_t wave_tile_add(uint32_t* counter, uint32_t tile, bool valid)
+{
+	const int MAXG = 12;
+	const uint32_t lane = threadIdx.x & 63;
+	unsigned long long todo = __ballot(valid);
+	int myLeader = (int)lane;
+	uint32_t myRank = 0, myCount = valid ? 1u : 0u;
+	for (int g = 0; g < MAXG && todo; g++) {
+		const int leader = __ffsll((long long)todo) - 1;
+		const uint32_t lt = __shfl(tile, leader, 64);
+		const unsigned long long peers = __ballot(valid && tile == lt) & todo;
+		if ((peers >> lane) & 1ull) {
+			myLeader = leader;
+			myRank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+			myCount = ((int)lane == leader) ? (uint32_t)__popcll(peers) : 0u;
+		}
+		todo &= ~peers;
+	}
+	uint32_t base = 0;
+	if (myCount) {
+		if (RETURNS) base = atomicAdd(&counter[tile], myCount);
+		else atomicAdd(&counter[tile], myCount);
+	}
+	if (RETURNS) base = __shfl(base, myLeader, 64) + myRank;
+	return base;
+}
+
+// ---------------------------------------------------------------------------
 struct ClipV { double x, y, z, w; };
 
 __device__ __forceinline__ double plane_dist(const ClipV& v, int plane, double VKR_GUARD)
@@ -135,12 +172,13 @@ __device__ __forceinline__ bool commit_subtri(const SetupArgs& a, uint32_t slot,
 	return true;
 }
 
+// fan triangles of a clipped polygon: slots after the one-per-triangle region
 __device__ __forceinline__ void emit_subtri(const SetupArgs& a, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2,
                                             int32_t Y2, const TriPlanes& pl, uint32_t prim, uint32_t flags, int cull)
 {
 	SubTri r; uint2 tiles;
 	if (!prepare_subtri(a, X0, Y0, X1, Y1, X2, Y2, pl, prim, flags, cull, r, tiles)) return;
-	commit_subtri(a, atomicAdd(a.recCount, 1u), r, tiles);
+	commit_subtri(a, a.count + atomicAdd(a.recCount, 1u), r, tiles);
 }
 
 __device__ __noinline__ void setup_clipped(const SetupArgs& a, float4 c0, float4 c1, float4 c2, const TriPlanes& pl,
@@ -158,86 +196,126 @@ __device__ __noinline__ void setup_clipped(const SetupArgs& a, float4 c0, float4
 	for (int i = 1; i + 1 < n; i++) emit_subtri(a, X[0], Y[0], X[i], Y[i], X[i + 1], Y[i + 1], pl, prim, flags, cull);
 }
 
-// One thread per triangle.  Unclipped triangles (the common case) allocate
-// their record slots with one atomic per wavefront; clipped ones take the
-// slow path.
+// What both setup kernels do first for triangle t: load, reject, planes, pass state.
+struct TriFront {
+	float4 c0, c1, c2;
+	TriPlanes pl;
+	uint32_t prim, flags;
+	int cull;
+	bool needClip;
+};
+
+__device__ __forceinline__ bool tri_front(const SetupArgs& a, uint32_t t, TriFront& f)
+{
+	const uint32_t i0 = a.sc.tri[3 * (size_t)t + 0], i1 = a.sc.tri[3 * (size_t)t + 1], i2 = a.sc.tri[3 * (size_t)t + 2];
+	const float4 c0 = a.clip[i0], c1 = a.clip[i1], c2 = a.clip[i2];
+	f.c0 = c0; f.c1 = c1; f.c2 = c2;
+	bool ok = true;
+	// NaN anywhere -> drop
+	if (!(c0.x == c0.x) || !(c0.y == c0.y) || !(c0.z == c0.z) || !(c0.w == c0.w)) ok = false;
+	if (!(c1.x == c1.x) || !(c1.y == c1.y) || !(c1.z == c1.z) || !(c1.w == c1.w)) ok = false;
+	if (!(c2.x == c2.x) || !(c2.y == c2.y) || !(c2.z == c2.z) || !(c2.w == c2.w)) ok = false;
+	// trivial reject against -w<=x,y<=w, 0<=z<=w
+	if ((c0.x < -c0.w) & (c1.x < -c1.w) & (c2.x < -c2.w)) ok = false;
+	if ((c0.x > c0.w) & (c1.x > c1.w) & (c2.x > c2.w)) ok = false;
+	if ((c0.y < -c0.w) & (c1.y < -c1.w) & (c2.y < -c2.w)) ok = false;
+	if ((c0.y > c0.w) & (c1.y > c1.w) & (c2.y > c2.w)) ok = false;
+	if ((c0.z < 0.0f) & (c1.z < 0.0f) & (c2.z < 0.0f)) ok = false;
+	if ((c0.z > c0.w) & (c1.z > c1.w) & (c2.z > c2.w)) ok = false;
+	if (!ok) return false;
+	if (!vkr_tri_planes(c0, c1, c2, a.view.W, a.view.H, f.pl)) return false;
+	const bool isAlphaMesh = t >= a.sc.nTriOpaque;
+	f.cull = isAlphaMesh ? a.cullAlpha : a.cullOpaque;
+	f.prim = a.useOrderB ? a.sc.orderB[t] : t;
+	f.flags = 0;
+	if (a.alphaTest && a.sc.mat[a.sc.triMat[t]].alphaTest) f.flags |= VKR_ST_ALPHA;
+	// does any vertex violate the near or a guard-band plane?
+	bool needClip = false;
+	const double G = a.guard;
+	const float4 c[3] = { c0, c1, c2 };
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+		double x = c[i].x, y = c[i].y, z = c[i].z, w = c[i].w;
+		if (!(z >= 0.0)) needClip = true;
+		if (!(x + G * w >= 0.0)) needClip = true;
+		if (!(G * w - x >= 0.0)) needClip = true;
+		if (!(y + G * w >= 0.0)) needClip = true;
+		if (!(G * w - y >= 0.0)) needClip = true;
+	}
+	f.needClip = needClip;
+	return true;
+}
+
+// One thread per triangle.  Unclipped triangles (the common case) write the
+// record slot of their own index; triangles that cross the
+// near plane or the guard band are queued for k_setup_clip, which keeps the
+// polygon clipper's local arrays (and their scratch memory) out of this kernel.
 __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 {
 	const uint32_t t = a.first + blockIdx.x * blockDim.x + threadIdx.x;
-	bool emit = false;
+	const uint32_t lane = threadIdx.x & 63;
+	bool emit = false, queue = false;
 	SubTri rec; uint2 tiles = make_uint2(0, 0);
 	if (t < a.first + a.count) {
-		const uint32_t i0 = a.sc.tri[3 * (size_t)t + 0], i1 = a.sc.tri[3 * (size_t)t + 1], i2 = a.sc.tri[3 * (size_t)t + 2];
-		const float4 c0 = a.clip[i0], c1 = a.clip[i1], c2 = a.clip[i2];
-		bool ok = true;
-		// NaN anywhere -> drop
-		if (!(c0.x == c0.x) || !(c0.y == c0.y) || !(c0.z == c0.z) || !(c0.w == c0.w)) ok = false;
-		if (!(c1.x == c1.x) || !(c1.y == c1.y) || !(c1.z == c1.z) || !(c1.w == c1.w)) ok = false;
-		if (!(c2.x == c2.x) || !(c2.y == c2.y) || !(c2.z == c2.z) || !(c2.w == c2.w)) ok = false;
-		// trivial reject against -w<=x,y<=w, 0<=z<=w
-		if ((c0.x < -c0.w) & (c1.x < -c1.w) & (c2.x < -c2.w)) ok = false;
-		if ((c0.x > c0.w) & (c1.x > c1.w) & (c2.x > c2.w)) ok = false;
-		if ((c0.y < -c0.w) & (c1.y < -c1.w) & (c2.y < -c2.w)) ok = false;
-		if ((c0.y > c0.w) & (c1.y > c1.w) & (c2.y > c2.w)) ok = false;
-		if ((c0.z < 0.0f) & (c1.z < 0.0f) & (c2.z < 0.0f)) ok = false;
-		if ((c0.z > c0.w) & (c1.z > c1.w) & (c2.z > c2.w)) ok = false;
-		TriPlanes pl;
-		if (ok && !vkr_tri_planes(c0, c1, c2, a.view.W, a.view.H, pl)) ok = false;
-		if (ok) {
-			const bool isAlphaMesh = t >= a.sc.nTriOpaque;
-			const int cull = isAlphaMesh ? a.cullAlpha : a.cullOpaque;
-			const uint32_t prim = a.useOrderB ? a.sc.orderB[t] : t;
-			uint32_t flags = 0;
-			if (a.alphaTest && a.sc.mat[a.sc.triMat[t]].alphaTest) flags |= VKR_ST_ALPHA;
-			const double hW = (double)a.view.W * 0.5, hH = (double)a.view.H * 0.5;
-			// does any vertex violate the near or a guard-band plane?
-			bool needClip = false;
-			const double VKR_GUARD = a.guard;
-			{
-				const float4 c[3] = { c0, c1, c2 };
-#pragma unroll
-				for (int i = 0; i < 3; i++) {
-					double x = c[i].x, y = c[i].y, z = c[i].z, w = c[i].w;
-					if (!(z >= 0.0)) needClip = true;
-					if (!(x + VKR_GUARD * w >= 0.0)) needClip = true;
-					if (!(VKR_GUARD * w - x >= 0.0)) needClip = true;
-					if (!(y + VKR_GUARD * w >= 0.0)) needClip = true;
-					if (!(VKR_GUARD * w - y >= 0.0)) needClip = true;
-				}
-			}
-			if (needClip) {
-				setup_clipped(a, c0, c1, c2, pl, prim, flags, cull, hW, hH);
+		TriFront f;
+		if (tri_front(a, t, f)) {
+			if (f.needClip) {
+				queue = true;
 			} else {
+				const double hW = (double)a.view.W * 0.5, hH = (double)a.view.H * 0.5;
 				int32_t X0, Y0, X1, Y1, X2, Y2;
-				snap_vertex(c0.x, c0.y, c0.w, hW, hH, X0, Y0);
-				snap_vertex(c1.x, c1.y, c1.w, hW, hH, X1, Y1);
-				snap_vertex(c2.x, c2.y, c2.w, hW, hH, X2, Y2);
-				emit = prepare_subtri(a, X0, Y0, X1, Y1, X2, Y2, pl, prim, flags, cull, rec, tiles);
+				snap_vertex(f.c0.x, f.c0.y, f.c0.w, hW, hH, X0, Y0);
+				snap_vertex(f.c1.x, f.c1.y, f.c1.w, hW, hH, X1, Y1);
+				snap_vertex(f.c2.x, f.c2.y, f.c2.w, hW, hH, X2, Y2);
+				emit = prepare_subtri(a, X0, Y0, X1, Y1, X2, Y2, f.pl, f.prim, f.flags, f.cull, rec, tiles);
 			}
 		}
 	}
-	// wave-aggregated slot allocation
-	const unsigned long long mask = __ballot(emit);
-	if (mask) {
-		const uint32_t lane = threadIdx.x & 63;
-		const int leader = __ffsll((long long)mask) - 1;
+	const unsigned long long qmask = __ballot(queue);
+	if (qmask) {
+		const int leader = __ffsll((long long)qmask) - 1;
 		uint32_t base = 0;
-		if ((int)lane == leader) base = atomicAdd(a.recCount, (uint32_t)__popcll(mask));
+		if ((int)lane == leader) base = atomicAdd(a.clipCount, (uint32_t)__popcll(qmask));
 		base = __shfl(base, leader, 64);
-		const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
-		const bool bigRec = emit && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 8;
-		bool stored = false;
-		if (emit) stored = commit_subtri(a, base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), rec, tiles, !bigRec);
-		// records that touch many tiles: the wave counts them together
-		unsigned long long bmask = __ballot(bigRec && stored);
-		while (bmask) {
-			const int src = __ffsll((long long)bmask) - 1;
-			bmask &= bmask - 1;
-			const uint32_t wx0 = __shfl(tx0, src, 64), wy0 = __shfl(ty0, src, 64);
-			const uint32_t wx1 = __shfl(tx1, src, 64), wy1 = __shfl(ty1, src, 64);
-			const uint32_t w = wx1 - wx0 + 1, cnt = w * (wy1 - wy0 + 1);
-			for (uint32_t k = lane; k < cnt; k += 64) atomicAdd(&a.tileCount[(wy0 + k / w) * a.view.tilesX + (wx0 + k % w)], 1u);
-		}
+		if (queue) a.clipQueue[base + (uint32_t)__popcll(qmask & ((1ull << lane) - 1ull))] = t;
+	}
+	// Record slot = triangle index inside the pass (no allocation: a counter
+	// every wave has to bump serialises in L2); slots of triangles that draw
+	// nothing carry an empty tile range.
+	const uint32_t slot = t - a.first;
+	if (t < a.first + a.count) {
+		if (emit) { a.recs[slot] = rec; a.recTiles[slot] = tiles; }
+		else a.recTiles[slot] = make_uint2(0xffffffffu, 0u);
+	}
+	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
+	const uint32_t nt = emit ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0u;
+	// one-tile records: grouped by tile inside the wave
+	wave_tile_add<false>(a.tileCount, ty0 * a.view.tilesX + tx0, nt == 1);
+	if (nt > 1 && nt <= 8)
+		for (uint32_t ty = ty0; ty <= ty1; ty++)
+			for (uint32_t tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tileCount[ty * a.view.tilesX + tx], 1u);
+	// records that touch many tiles: the wave counts them together
+	unsigned long long bmask = __ballot(nt > 8);
+	while (bmask) {
+		const int src = __ffsll((long long)bmask) - 1;
+		bmask &= bmask - 1;
+		const uint32_t wx0 = __shfl(tx0, src, 64), wy0 = __shfl(ty0, src, 64);
+		const uint32_t wx1 = __shfl(tx1, src, 64), wy1 = __shfl(ty1, src, 64);
+		const uint32_t w = wx1 - wx0 + 1, cnt = w * (wy1 - wy0 + 1);
+		for (uint32_t k = lane; k < cnt; k += 64) atomicAdd(&a.tileCount[(wy0 + k / w) * a.view.tilesX + (wx0 + k % w)], 1u);
+	}
+}
+
+// The queued triangles: polygon clip, fan, one record per fan triangle.
+__global__ __launch_bounds__(64) void k_setup_clip(SetupArgs a)
+{
+	const uint32_t n = *a.clipCount;
+	for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+		const uint32_t t = a.clipQueue[q];
+		TriFront f;
+		if (!tri_front(a, t, f)) continue;
+		const double hW = (double)a.view.W * 0.5, hH = (double)a.view.H * 0.5;
+		setup_clipped(a, f.c0, f.c1, f.c2, f.pl, f.prim, f.flags, f.cull, hW, hH);
 	}
 }
 
@@ -278,22 +356,36 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 	}
 }
 
-// One thread per record; a record that touches more than 8 tiles is spread
-// over the whole wavefront.
+// One thread per record slot; a record that touches more than 8 tiles is
+// spread over the whole wavefront.
 __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 {
 	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t n = min(*a.recCount, a.recCap);
-	const bool has = r < n;
+	const uint32_t n = min(a.baseCount + *a.recCount, a.recCap);
+	bool has = r < n;
 	uint32_t tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0, key = 0;
+	uint2 tr = make_uint2(0xffffffffu, 0u);
+	if (has) tr = a.recTiles[r];
+	has = tr.x != 0xffffffffu; // slot of a triangle that draws nothing
 	if (has) {
-		const uint2 tr = a.recTiles[r];
 		tx0 = tr.x & 0xffffu; ty0 = tr.x >> 16; tx1 = tr.y & 0xffffu; ty1 = tr.y >> 16;
 		if (a.keys) key = a.recs[r].prim;
 	}
 	const uint32_t nt = has ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0;
 	const bool big = nt > 8;
-	if (has && !big) {
+	{
+		// one-tile records: one atomic per group of lanes that share the tile
+		const uint32_t tile = ty0 * a.tilesX + tx0;
+		const uint32_t local = wave_tile_add<true>(a.cursor, tile, nt == 1);
+		if (nt == 1) {
+			const uint32_t idx = a.tileOffset[tile] + local;
+			if (idx < a.binCap) {
+				a.binList[idx] = r;
+				if (a.keys) a.keys[idx] = key;
+			}
+		}
+	}
+	if (has && !big && nt > 1) {
 		for (uint32_t ty = ty0; ty <= ty1; ty++)
 			for (uint32_t tx = tx0; tx <= tx1; tx++) {
 				const uint32_t tile = ty * a.tilesX + tx;
@@ -335,6 +427,8 @@ void vkr_launch_setup(hipStream_t s, const SetupArgs& a)
 {
 	if (!a.count) return;
 	hipLaunchKernelGGL(k_setup, dim3((a.count + 255) / 256), dim3(256), 0, s, a);
+	// few triangles need the clipper; a fixed grid strides over however many were queued
+	hipLaunchKernelGGL(k_setup_clip, dim3(512), dim3(64), 0, s, a);
 }
 
 void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, uint32_t* offset, uint32_t* cursor, uint32_t nTiles,

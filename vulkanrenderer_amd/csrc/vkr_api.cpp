@@ -96,7 +96,7 @@ struct vkr_context {
 	float* dThresh = nullptr; // 255
 	float hDecode[256], hThresh[255];
 	// geometry scratch
-	DevBuf clip, recs, recTiles, counters, tileCount, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
+	DevBuf clip, recs, recTiles, clipQueue, counters, tileCount, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
 	uint32_t recCap = 0, binCap = 0;
 	double capScale = 1.0;
 	// frame buffers
@@ -317,7 +317,7 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf* bufs[] = { &c->clip, &c->recs, &c->recTiles, &c->counters, &c->tileCount, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
+	DevBuf* bufs[] = { &c->clip, &c->recs, &c->recTiles, &c->clipQueue, &c->counters, &c->tileCount, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
 		&c->binKeys, &c->binList2, &c->binKeys2, &c->sortTemp, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
 		&c->colour2, &c->stencil, &c->mip, &c->shadow };
 	for (DevBuf* b : bufs) b->release();
@@ -643,12 +643,14 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 {
 	const uint32_t nTiles = g.view.tilesX * g.view.tilesY;
 	if (nTiles == 0 || nTiles > (1u << 24)) return set_error(VKR_E_LIMIT, "tile count %u out of range", nTiles);
-	const uint32_t recCap = (uint32_t)std::min<double>(4.0e9, ((double)g.count * 1.25 + 4096.0) * c->capScale);
+	// one slot per triangle + room for the fan triangles of clipped ones
+	const uint32_t recCap = (uint32_t)std::min<double>(4.0e9, (double)g.count + ((double)g.count * 0.25 + 4096.0) * c->capScale);
 	const uint32_t binCap = (uint32_t)std::min<double>(4.0e9, ((double)recCap * 3.0 + nTiles) * c->capScale);
 	int rc;
 	if ((rc = c->clip.ensure((size_t)s->dev.nVert * sizeof(float4)))) return rc;
 	if ((rc = c->recs.ensure((size_t)recCap * sizeof(SubTri)))) return rc;
 	if ((rc = c->recTiles.ensure((size_t)recCap * sizeof(uint2)))) return rc;
+	if ((rc = c->clipQueue.ensure((size_t)(g.count ? g.count : 1) * 4))) return rc;
 	if ((rc = c->counters.ensure(64))) return rc;
 	if ((rc = c->tileCount.ensure((size_t)nTiles * 4))) return rc;
 	if ((rc = c->tileOffset.ensure((size_t)(nTiles + 1) * 4))) return rc;
@@ -657,7 +659,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if ((rc = c->binList.ensure((size_t)binCap * 4))) return rc;
 	if (g.keys && (rc = c->binKeys.ensure((size_t)binCap * 4))) return rc;
 	c->recCap = recCap; c->binCap = binCap;
-	uint32_t* counters = c->counters.as<uint32_t>(); // [0] recCount, [1] overflow
+	uint32_t* counters = c->counters.as<uint32_t>(); // [0] recCount, [1] overflow, [2] alpha tile count, [3] clip queue length
 	HIP_CHECK(hipMemsetAsync(counters, 0, 64, c->stream));
 	HIP_CHECK(hipMemsetAsync(c->tileCount.p, 0, (size_t)nTiles * 4, c->stream));
 	{
@@ -673,6 +675,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 		a.guard = vkr_guard_band(g.view.W, g.view.H);
 		a.recs = c->recs.as<SubTri>(); a.recTiles = c->recTiles.as<uint2>(); a.recCap = recCap;
 		a.recCount = counters; a.tileCount = c->tileCount.as<uint32_t>(); a.overflow = counters + 1;
+		a.clipQueue = c->clipQueue.as<uint32_t>(); a.clipCount = counters + 3;
 		vkr_launch_setup(c->stream, a);
 	}
 	{
@@ -683,7 +686,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	{
 		StageTimer t(c, ST_BIN_FILL);
 		BinFillArgs b;
-		b.recs = c->recs.as<SubTri>(); b.recTiles = c->recTiles.as<uint2>(); b.recCount = counters; b.recCap = recCap;
+		b.recs = c->recs.as<SubTri>(); b.recTiles = c->recTiles.as<uint2>(); b.recCount = counters; b.baseCount = g.count; b.recCap = recCap;
 		b.tileOffset = c->tileOffset.as<uint32_t>(); b.cursor = c->cursor.as<uint32_t>(); b.binList = c->binList.as<uint32_t>();
 		b.keys = g.keys ? c->binKeys.as<uint32_t>() : nullptr; b.binCap = binCap; b.tilesX = g.view.tilesX;
 		vkr_launch_bin_fill(c->stream, b, recCap);

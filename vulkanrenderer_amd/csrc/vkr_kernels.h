@@ -15,15 +15,18 @@ struct SetupArgs {
 	SubTri* recs;
 	uint2* recTiles;
 	uint32_t recCap;
-	uint32_t* recCount;
+	uint32_t* recCount;   // records of clipped triangles, stored from slot `count` on
 	uint32_t* tileCount;
 	uint32_t* overflow;
+	uint32_t* clipQueue;  // triangles that need the polygon clipper (capacity: count)
+	uint32_t* clipCount;  // zeroed by the caller
 };
 
 struct BinFillArgs {
 	const SubTri* recs;
 	const uint2* recTiles;
-	const uint32_t* recCount;
+	const uint32_t* recCount; // records appended after the one-per-triangle slots
+	uint32_t baseCount;       // triangles of the pass = one-per-triangle slots
 	uint32_t recCap;
 	const uint32_t* tileOffset;
 	uint32_t* cursor;
