@@ -209,197 +209,155 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 // ---------------------------------------------------------------------------
 // Second visibility pass: the alpha-tested sub-triangles (discard on
 // alpha < 0.5, gBufWrite.frag:22-23 / default.frag:91-92) of the tiles that
-// hold any.  The tile comes back from HBM into LDS with every opaque fragment
-// in it, and a hierarchical depth test keeps most of the work away from the
-// texture:
-//   - per 8x8 block the farthest stored depth is kept in LDS; a sub-triangle
-//     whose nearest possible depth over a block lies behind it skips the block;
-//   - inside a block, fragments behind the stored depth are dropped;
-//   - the survivors are packed into a per-wave queue and alpha-tested 64 at a
-//     time with every lane busy.
-// Interpolation planes are computed once per sub-triangle, lane-parallel, and
-// staged in LDS; each wave walks its sub-triangles near-to-far.
+// hold any.  One 1024-thread workgroup per such tile, pixel-owner: wavefront w
+// owns the 8x8 block w of the tile and every lane one pixel, whose
+// (depth | primitive) key it keeps in registers, seeded from the opaque pass.
+// The tile's alpha-tested bin entries are staged through LDS 256 at a time
+// (edge functions, depth plane, interpolation planes, texture description,
+// computed once per entry), and every wavefront walks the staged list:
+//   - entries whose bounding box misses the block, or whose nearest possible
+//     depth over the block lies behind the block's farthest stored depth, cost a
+//     few scalar-uniform instructions;
+//   - a lane runs the alpha test only if its fragment is covered, inside the
+//     depth range and not behind what it already holds.
+// No atomics: each pixel has one owner, and the result does not depend on the
+// order of the entries (the key minimum is order-free; a skipped fragment
+// could not have won).
 // ---------------------------------------------------------------------------
-struct AlphaStage {
-	double a[3], b[3], c[3];
-	float2 t0, t1, t2;
-	uint32_t tex;
-	uint32_t ok;
+#define ALPHA_CHUNK 256
+
+struct AlphaCover {          // coverage + depth of one staged entry
+	double e0, e1, e2;       // biased edge values at the tile's first pixel centre
+	double sx0, sx1, sx2;    // per pixel in x
+	double sy0, sy1, sy2;    // per pixel in y
+	double Az, Bz, Cz;
+	uint32_t prim;
+	uint32_t bbox;           // tile-local inclusive x0 | y0 << 8 | x1 << 16 | y1 << 24
 };
 
-// farthest depth stored in the 8x8 block the wave's lanes map onto
-__device__ __forceinline__ uint32_t block_max_depth(const unsigned long long* tb64, int bxl, int byl, uint32_t lane)
+struct AlphaAttr {           // what the alpha test of a fragment needs
+	double a[3], b[3], c[3];
+	float2 t0, t1, t2;
+	uint32_t off0, w0, h0;
+	int levels;
+};
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-	uint32_t d = (uint32_t)(tb64[(byl * 8 + (int)(lane >> 3)) * VKR_TILE + bxl * 8 + (int)(lane & 7)] >> 32);
 #pragma unroll
-	for (int k = 32; k >= 1; k >>= 1) d = max(d, (uint32_t)__shfl_xor((int)d, k, 64));
-	return d;
+	for (int k = 32; k >= 1; k >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, k, 64));
+	return v;
 }
 
-__global__ __launch_bounds__(256) void k_raster_alpha(RasterArgs a)
+__global__ __launch_bounds__(1024) void k_raster_alpha(RasterArgs a)
 {
-	// work item = (tile with alpha-tested entries, slice of its bin): a dense tile is spread over
-	// VKR_ALPHA_SLICES workgroups, each with its own LDS copy of the tile, merged by atomicMin
 	const uint32_t nAlpha = min(a.alphaTileCount[0], a.view.tilesX * a.view.tilesY);
-	if (blockIdx.x / VKR_ALPHA_SLICES >= nAlpha) return;
-	const uint32_t tile = a.alphaTiles[blockIdx.x / VKR_ALPHA_SLICES], slice = blockIdx.x % VKR_ALPHA_SLICES;
-	__shared__ unsigned long long tb64[VKR_TILE_PIX];
-	__shared__ AlphaStage stage[256];
-	__shared__ uint16_t sQueue[4 * 128];
-	__shared__ uint32_t sBlockMax[16]; // depth bits; stale values are only ever too far (conservative)
-	uint32_t* tb32 = nullptr; // unused, keeps fragment<>'s signature
+	if (blockIdx.x >= nAlpha) return;
+	const uint32_t tile = a.alphaTiles[blockIdx.x];
+	__shared__ AlphaCover sCov[ALPHA_CHUNK];
+	__shared__ AlphaAttr sAttr[ALPHA_CHUNK];
+	__shared__ uint32_t sCount;
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
 	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = (int)(a.view.y0 + ty * VKR_TILE);
 	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = min(oy + VKR_TILE, (int)a.view.y1) - 1;
-	const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wbase = tid & ~63u;
-	uint16_t* wq = &sQueue[wid * 128];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const int bxl = (int)(wid & 3) * 8, byl = (int)(wid >> 2) * 8;    // the wave's block, tile-local
+	const int lx = bxl + (int)(lane & 7), ly = byl + (int)(lane >> 3); // the lane's pixel, tile-local
+	const int px = ox + lx, py = oy + ly;
+	const bool inRect = px <= ex && py <= ey;
 	const uint32_t rw = a.view.x1 - a.view.x0;
-
-	for (uint32_t i = tid; i < VKR_TILE_PIX; i += 256) {
-		const int px = ox + (int)(i % VKR_TILE), py = oy + (int)(i / VKR_TILE);
-		unsigned long long v = 0ull; // outside the rectangle: nothing can be nearer
-		if (px <= ex && py <= ey) v = a.vis[(size_t)(py - (int)a.view.y0) * rw + (size_t)(px - (int)a.view.x0)];
-		tb64[i] = v;
-	}
-	__syncthreads();
-	for (int b = (int)wid; b < 16; b += 4) {
-		const uint32_t m = block_max_depth(tb64, b & 3, b >> 2, lane);
-		if (lane == 0) sBlockMax[b] = m;
-	}
+	const size_t p = (size_t)(py - (int)a.view.y0) * rw + (size_t)(px - (int)a.view.x0);
+	unsigned long long key = inRect ? a.vis[p] : 0ull;
+	uint32_t wmax = wave_max_u32(inRect ? (uint32_t)(key >> 32) : 0u); // farthest depth held in the block
+	const double dlx = (double)lx, dly = (double)ly;
+	const double bcx = (double)(ox + bxl) + 4.0, bcy = (double)(oy + byl) + 4.0; // block centre (between pixel centres)
 
 	uint32_t beg = a.tileOffset[tile], end = a.tileOffset[tile + 1];
 	if (end > a.binCap) end = a.binCap;
 	if (beg > end) beg = end;
 	const uint32_t n = end - beg;
-	if (slice * 256 >= n) return;
 
-	for (uint32_t base = slice * 256; base < n; base += VKR_ALPHA_SLICES * 256) {
-		const uint32_t i = base + tid;
-		bool has = i < n;
-		SubTri s;
-		int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
-		if (has) {
-			const uint32_t ri = a.binList[beg + i];
-			has = (a.recs[ri].flags & VKR_ST_ALPHA) != 0;
-			if (has) s = a.recs[ri];
-		}
-		if (has) {
-			tri_bbox(s, bx0, by0, bx1, by1);
-			bx0 = max(bx0, ox); by0 = max(by0, oy); bx1 = min(bx1, ex); by1 = min(by1, ey);
-		} else {
-			s.X0 = s.Y0 = s.X1 = s.Y1 = s.X2 = s.Y2 = 0; s.prim = 0; s.flags = 0; s.Az = s.Bz = s.Cz = s.bias = 0.0;
-		}
-		const bool nonEmpty = has && bx0 <= bx1 && by0 <= by1;
-		if (nonEmpty) {
-			// alpha-tested passes submit in order A, so prim indexes sc.tri directly
-			const uint32_t i0 = a.sc.tri[3 * (size_t)s.prim + 0], i1 = a.sc.tri[3 * (size_t)s.prim + 1],
-			               i2 = a.sc.tri[3 * (size_t)s.prim + 2];
-			TriPlanes pl;
-			AlphaStage& st = stage[tid];
-			st.ok = vkr_tri_planes<false>(a.clip[i0], a.clip[i1], a.clip[i2], a.view.W, a.view.H, pl) ? 1u : 0u;
-#pragma unroll
-			for (int k = 0; k < 3; k++) { st.a[k] = pl.a[k]; st.b[k] = pl.b[k]; st.c[k] = pl.c[k]; }
-			st.t0 = make_float2(a.sc.uv[2 * (size_t)i0], a.sc.uv[2 * (size_t)i0 + 1]);
-			st.t1 = make_float2(a.sc.uv[2 * (size_t)i1], a.sc.uv[2 * (size_t)i1 + 1]);
-			st.t2 = make_float2(a.sc.uv[2 * (size_t)i2], a.sc.uv[2 * (size_t)i2 + 1]);
-			st.tex = a.sc.mat[a.sc.triMat[s.prim]].tex[3];
-		}
-		// near entries first: 8 rounds over the depth (at the tile centre) range of the wave's entries
-		const float zc = nonEmpty ? fminf(fmaxf(vkr_depth_at(s.Az, s.Bz, s.Cz, ox + VKR_TILE / 2, oy + VKR_TILE / 2), 0.0f), 1.0f) : 2.0f;
-		float zlo = nonEmpty ? zc : 2.0f, zhi = nonEmpty ? zc : -1.0f;
-#pragma unroll
-		for (int d = 32; d >= 1; d >>= 1) {
-			zlo = fminf(zlo, __shfl_xor(zlo, d, 64));
-			zhi = fmaxf(zhi, __shfl_xor(zhi, d, 64));
-		}
-		const float zscale = (zhi > zlo) ? 7.999f / (zhi - zlo) : 0.0f;
-		const int bucket = nonEmpty ? (int)((zc - zlo) * zscale) : -1;
+	for (uint32_t base = 0; base < n; base += ALPHA_CHUNK) {
+		if (tid == 0) sCount = 0;
 		__syncthreads();
-
-		for (int round = 0; round < 8; round++) {
-			unsigned long long mask = __ballot(bucket == round);
-			while (mask) {
-				const int src = __ffsll((long long)mask) - 1;
-				mask &= mask - 1;
-				SubTri w;
-				int wx0, wy0, wx1, wy1;
-				bcast_subtri(s, bx0, by0, bx1, by1, src, w, wx0, wy0, wx1, wy1);
-				const AlphaStage& st = stage[wbase + (uint32_t)src];
-				if (!st.ok) continue;
-				TriPlanes pl;
+		if (tid < ALPHA_CHUNK && base + tid < n) {
+			const uint32_t ri = a.binList[beg + base + tid];
+			const SubTri s = a.recs[ri];
+			if (s.flags & VKR_ST_ALPHA) {
+				int bx0, by0, bx1, by1;
+				tri_bbox(s, bx0, by0, bx1, by1);
+				bx0 = max(bx0, ox); by0 = max(by0, oy); bx1 = min(bx1, ex); by1 = min(by1, ey);
+				if (bx0 <= bx1 && by0 <= by1) {
+					// alpha-tested passes submit in order A, so prim indexes sc.tri directly
+					const uint32_t i0 = a.sc.tri[3 * (size_t)s.prim + 0], i1 = a.sc.tri[3 * (size_t)s.prim + 1],
+					               i2 = a.sc.tri[3 * (size_t)s.prim + 2];
+					TriPlanes pl;
+					if (vkr_tri_planes<false>(a.clip[i0], a.clip[i1], a.clip[i2], a.view.W, a.view.H, pl)) {
+						const uint32_t slot = atomicAdd(&sCount, 1u);
+						AlphaCover& c = sCov[slot];
+						EdgeSetup E;
+						edge_setup(s, ox, oy, E);
+						c.e0 = E.e0; c.e1 = E.e1; c.e2 = E.e2;
+						c.sx0 = E.sx0; c.sx1 = E.sx1; c.sx2 = E.sx2;
+						c.sy0 = E.sy0; c.sy1 = E.sy1; c.sy2 = E.sy2;
+						c.Az = s.Az; c.Bz = s.Bz; c.Cz = s.Cz;
+						c.prim = s.prim;
+						c.bbox = (uint32_t)(bx0 - ox) | ((uint32_t)(by0 - oy) << 8) | ((uint32_t)(bx1 - ox) << 16) | ((uint32_t)(by1 - oy) << 24);
+						AlphaAttr& t = sAttr[slot];
 #pragma unroll
-				for (int k = 0; k < 3; k++) { pl.a[k] = st.a[k]; pl.b[k] = st.b[k]; pl.c[k] = st.c[k]; }
-				pl.Az = pl.Bz = pl.Cz = 0.0;
-				const float2 t0 = st.t0, t1 = st.t1, t2 = st.t2;
-				const TexInfo& tex = a.sc.tex[st.tex];
-				const int lx = (int)(lane & 7), ly = (int)(lane >> 3);
-				// walk the tile's own 8x8 blocks that the clipped bounding box touches
-				const int cbx0 = (wx0 - ox) >> 3, cbx1 = (wx1 - ox) >> 3, cby0 = (wy0 - oy) >> 3, cby1 = (wy1 - oy) >> 3;
-				EdgeSetup E;
-				edge_setup(w, ox + cbx0 * 8 + lx, oy + cby0 * 8 + ly, E);
-				const double bx0s = E.sx0 * 8.0, bx1s = E.sx1 * 8.0, bx2s = E.sx2 * 8.0;
-				const double by0s = E.sy0 * 8.0, by1s = E.sy1 * 8.0, by2s = E.sy2 * 8.0;
-				// nearest depth the plane can take over a block, measured from the block's first pixel centre
-				const float zslack = (float)(3.5 * (fabs(w.Az) + fabs(w.Bz))) + 2.0e-6f;
-				double r0 = E.e0, r1 = E.e1, r2 = E.e2;
-				uint32_t qn = 0;   // candidates waiting in this wave's queue
-				uint32_t wrote = 0; // bit b set: block b received a fragment from this sub-triangle
-				for (int cby = cby0; cby <= cby1; cby++) {
-					double e0 = r0, e1 = r1, e2 = r2;
-					for (int cbx = cbx0; cbx <= cbx1; cbx++) {
-						const double f0 = e0, f1 = e1, f2 = e2;
-						e0 += bx0s; e1 += bx1s; e2 += bx2s;
-						const int b = cby * 4 + cbx;
-						// block-level depth rejection (uniform across the wave)
-						const float zmid = (float)fma(w.Az, (double)(ox + cbx * 8) + 4.0, fma(w.Bz, (double)(oy + cby * 8) + 4.0, w.Cz));
-						const float znear = zmid - zslack;
-						if (znear > u2f(sBlockMax[b])) continue;
-						const int px = ox + cbx * 8 + lx, py = oy + cby * 8 + ly;
-						const bool in = px >= wx0 && px <= wx1 && py >= wy0 && py <= wy1 && edges_inside(f0, f1, f2);
-						const int li = (py - oy) * VKR_TILE + (px - ox);
-						bool cand = false;
-						if (in) {
-							const float z = vkr_depth_at(w.Az, w.Bz, w.Cz, px, py);
-							cand = (z >= 0.0f && z <= 1.0f) && !(f2u(z) > (uint32_t)(tb64[li] >> 32));
-						}
-						const unsigned long long cm = __ballot(cand);
-						if (cm == 0) continue;
-						wrote |= 1u << b;
-						if (cand) wq[qn + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = (uint16_t)li;
-						qn += (uint32_t)__popcll(cm);
-						if (qn >= 64) {
-							const int qi = (int)wq[lane];
-							const int qx = ox + (qi % VKR_TILE), qy = oy + (qi / VKR_TILE);
-							if (alpha_pass(a, pl, t0, t1, t2, tex, qx, qy)) fragment<RASTER_VIS>(tb64, tb32, qi, w, qx, qy);
-							const uint16_t carry = wq[64 + lane];
-							qn -= 64;
-							if (lane < qn) wq[lane] = carry;
-						}
+						for (int k = 0; k < 3; k++) { t.a[k] = pl.a[k]; t.b[k] = pl.b[k]; t.c[k] = pl.c[k]; }
+						t.t0 = make_float2(a.sc.uv[2 * (size_t)i0], a.sc.uv[2 * (size_t)i0 + 1]);
+						t.t1 = make_float2(a.sc.uv[2 * (size_t)i1], a.sc.uv[2 * (size_t)i1 + 1]);
+						t.t2 = make_float2(a.sc.uv[2 * (size_t)i2], a.sc.uv[2 * (size_t)i2 + 1]);
+						const TexInfo& tex = a.sc.tex[a.sc.mat[a.sc.triMat[s.prim]].tex[3]];
+						t.off0 = tex.offset[0]; t.w0 = tex.w[0]; t.h0 = tex.h[0]; t.levels = tex.levels;
 					}
-					r0 += by0s; r1 += by1s; r2 += by2s;
-				}
-				if (lane < qn) {
-					const int qi = (int)wq[lane];
-					const int qx = ox + (qi % VKR_TILE), qy = oy + (qi / VKR_TILE);
-					if (alpha_pass(a, pl, t0, t1, t2, tex, qx, qy)) fragment<RASTER_VIS>(tb64, tb32, qi, w, qx, qy);
-				}
-				// refresh the farthest depth of the blocks that may have changed
-				while (wrote) {
-					const int b = __ffs((int)wrote) - 1;
-					wrote &= wrote - 1;
-					const uint32_t m = block_max_depth(tb64, b & 3, b >> 2, lane);
-					if (lane == 0) sBlockMax[b] = m;
 				}
 			}
 		}
+		__syncthreads();
+		const uint32_t m = sCount;
+		for (uint32_t j = 0; j < m; j++) {
+			const AlphaCover& c = sCov[j];
+			const uint32_t bb = c.bbox;
+			const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
+			if (x1 < bxl || x0 > bxl + 7 || y1 < byl || y0 > byl + 7) continue; // misses the block (wave-uniform)
+			const double Az = c.Az, Bz = c.Bz, Cz = c.Cz;
+			// nearest depth the plane can take over the block's pixel centres
+			const float znear = (float)fma(Az, bcx, fma(Bz, bcy, Cz)) - ((float)(3.5 * (fabs(Az) + fabs(Bz))) + 2.0e-6f);
+			if (znear > u2f(wmax)) continue;
+			// exact: integers below 2^53
+			const double e0 = fma(c.sy0, dly, fma(c.sx0, dlx, c.e0));
+			const double e1 = fma(c.sy1, dly, fma(c.sx1, dlx, c.e1));
+			const double e2 = fma(c.sy2, dly, fma(c.sx2, dlx, c.e2));
+			bool cand = inRect && lx >= x0 && lx <= x1 && ly >= y0 && ly <= y1 && edges_inside(e0, e1, e2);
+			float z = 0.0f;
+			if (cand) {
+				z = vkr_depth_at(Az, Bz, Cz, px, py);
+				cand = (z >= 0.0f && z <= 1.0f) && !(f2u(z) > (uint32_t)(key >> 32));
+			}
+			if (__ballot(cand) == 0ull) continue;
+			bool upd = false;
+			if (cand) {
+				const AlphaAttr& t = sAttr[j];
+				TriPlanes pl;
+#pragma unroll
+				for (int k = 0; k < 3; k++) { pl.a[k] = t.a[k]; pl.b[k] = t.b[k]; pl.c[k] = t.c[k]; }
+				pl.Az = pl.Bz = pl.Cz = 0.0;
+				float b[3], uv[2], d[4];
+				vkr_bary_at(pl, px, py, b);
+				vkr_uv_derivs(pl, px, py, b, t.t0, t.t1, t.t2, uv, d);
+				const float alpha = vkr_trilinear_alpha_wh(a.sc.texels, t.off0, t.w0, t.h0, t.levels, uv[0], uv[1], d);
+				if (!(alpha < 0.5f)) {
+					const unsigned long long k2 = ((unsigned long long)f2u(z) << 32) | (unsigned long long)(0xFFFFFFFEu - c.prim);
+					if (k2 < key) { key = k2; upd = true; }
+				}
+			}
+			if (__ballot(upd)) wmax = wave_max_u32(inRect ? (uint32_t)(key >> 32) : 0u);
+		}
 		__syncthreads(); // the stage is rewritten by the next chunk
 	}
-	__syncthreads();
-	for (uint32_t i = tid; i < VKR_TILE_PIX; i += 256) {
-		const int px = ox + (int)(i % VKR_TILE), py = oy + (int)(i / VKR_TILE);
-		if (px > ex || py > ey) continue;
-		atomicMin(&a.vis[(size_t)(py - (int)a.view.y0) * rw + (size_t)(px - (int)a.view.x0)], tb64[i]);
-	}
+	if (inRect) a.vis[p] = key;
 }
 
 // ---------------------------------------------------------------------------
@@ -469,7 +427,7 @@ void vkr_launch_raster(hipStream_t s, int mode, const RasterArgs& a)
 	if (!nTiles) return;
 	if (mode == RASTER_VIS) {
 		hipLaunchKernelGGL(k_raster<RASTER_VIS>, dim3(nTiles), dim3(256), 0, s, a);
-		if (a.alphaPass) hipLaunchKernelGGL(k_raster_alpha, dim3(nTiles * VKR_ALPHA_SLICES), dim3(256), 0, s, a);
+		if (a.alphaPass) hipLaunchKernelGGL(k_raster_alpha, dim3(nTiles), dim3(1024), 0, s, a);
 	}
 	else if (mode == RASTER_SHADOW) hipLaunchKernelGGL(k_raster<RASTER_SHADOW>, dim3(nTiles), dim3(256), 0, s, a);
 	else hipLaunchKernelGGL(k_raster<RASTER_COUNT>, dim3(nTiles), dim3(256), 0, s, a);

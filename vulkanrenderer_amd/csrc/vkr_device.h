@@ -305,15 +305,15 @@ __device__ __forceinline__ void vkr_lod_split(float rho2, int q, int& d, float& 
 	d = lv; f = fr;
 }
 
-__device__ __forceinline__ float vkr_rho2(const TexInfo& t, const float d[4])
+__device__ __forceinline__ float vkr_rho2_wh(float tw, float th, const float d[4])
 {
-	float tw = (float)t.w[0], th = (float)t.h[0];
 	float mx = d[0] * tw, my = d[1] * th;
 	float nx = d[2] * tw, ny = d[3] * th;
 	float rx = fmaf(my, my, mx * mx);
 	float ry = fmaf(ny, ny, nx * nx);
 	return (rx > ry) ? rx : ry;
 }
+__device__ __forceinline__ float vkr_rho2(const TexInfo& t, const float d[4]) { return vkr_rho2_wh((float)t.w[0], (float)t.h[0], d); }
 
 __device__ __forceinline__ int vkr_wrap(int i, int n)
 {
@@ -362,10 +362,10 @@ __device__ __forceinline__ bool vkr_same_dims(const TexInfo& t, const TexTaps& t
 	return t.w[0] == tp.w0 && t.h[0] == tp.h0 && t.levels == tp.levels;
 }
 
-__device__ __forceinline__ void vkr_make_taps(const TexInfo& t, float u, float v, const float d[4], TexTaps& tp)
+__device__ __forceinline__ void vkr_make_taps_wh(uint32_t w0, uint32_t h0, int levels, float u, float v, const float d[4], TexTaps& tp)
 {
-	tp.w0 = t.w[0]; tp.h0 = t.h[0]; tp.levels = t.levels;
-	vkr_lod_split(vkr_rho2(t, d), t.levels - 1, tp.lv, tp.fr);
+	tp.w0 = w0; tp.h0 = h0; tp.levels = levels;
+	vkr_lod_split(vkr_rho2_wh((float)w0, (float)h0, d), levels - 1, tp.lv, tp.fr);
 	// level sizes halve, rounding down, not below 1 (utils/vkimage.cpp:165-197)
 	int w = (int)(tp.w0 >> tp.lv), h = (int)(tp.h0 >> tp.lv);
 	if (w < 1) w = 1;
@@ -377,6 +377,21 @@ __device__ __forceinline__ void vkr_make_taps(const TexInfo& t, float u, float v
 		if (h1 < 1) h1 = 1;
 		vkr_level_taps(w1, h1, u, v, tp.t1);
 	}
+}
+__device__ __forceinline__ void vkr_make_taps(const TexInfo& t, float u, float v, const float d[4], TexTaps& tp)
+{
+	vkr_make_taps_wh(t.w[0], t.h[0], t.levels, u, v, d, tp);
+}
+
+// texel offset of level lv of a full mip chain that starts at off0 (levels are stored back to back)
+__device__ __forceinline__ uint32_t vkr_level_offset(uint32_t off0, uint32_t w0, uint32_t h0, int lv)
+{
+	uint32_t off = off0;
+	for (int k = 0; k < lv; k++) {
+		uint32_t w = w0 >> k, h = h0 >> k;
+		off += (w ? w : 1u) * (h ? h : 1u);
+	}
+	return off;
 }
 
 // channel c (0..2 colour, 3 alpha) of a packed texel; dec = 256-entry sRGB decode table or nullptr for UNORM
@@ -413,6 +428,23 @@ __device__ __forceinline__ void vkr_fetch(const SceneDev& sc, const TexInfo& t, 
 #pragma unroll
 	for (int c = 0; c < 4; c++)
 		if (MASK & (1 << c)) out[c] = vkr_lerp(a[c], b[c], tp.fr);
+}
+
+// .a of texture(sampler, uv) for a texture described by (off0, w0, h0, levels): the alpha test needs
+// nothing else, and with the level offsets recomputed the texel loads are the only memory round trip
+__device__ __forceinline__ float vkr_trilinear_alpha_wh(const uint32_t* __restrict__ texels, uint32_t off0, uint32_t w0, uint32_t h0,
+                                                        int levels, float u, float v, const float d[4])
+{
+	TexTaps tp;
+	vkr_make_taps_wh(w0, h0, levels, u, v, d, tp);
+	const uint32_t o0 = vkr_level_offset(off0, w0, h0, tp.lv);
+	float a[4], b[4];
+	vkr_bilinear_taps<8>(texels + o0, tp.t0, nullptr, a);
+	if (tp.fr == 0.0f) return a[3];
+	uint32_t w = w0 >> tp.lv, h = h0 >> tp.lv;
+	const uint32_t o1 = o0 + (w ? w : 1u) * (h ? h : 1u);
+	vkr_bilinear_taps<8>(texels + o1, tp.t1, nullptr, b);
+	return vkr_lerp(a[3], b[3], tp.fr);
 }
 
 // one-off trilinear fetch (all four channels)
