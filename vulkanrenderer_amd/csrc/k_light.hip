@@ -23,7 +23,10 @@
 //    the loop accumulates S1 = sum t(1-x^5), S2 = sum t spec, S3 = sum t spec x^5
 //    (t = N.L/d^2) and the channels are combined once at the end.
 //  * max(.,0) of quantities bounded by 1 uses the free clamp modifier.
-// Per light: 42 plain VALU instructions and 5 transcendentals (2 rsq, 2 rcp, 1 exp2).
+// Per light: 42 plain VALU instructions and 5 transcendentals (2 rsq, 2 rcp, 1 exp2).  Measured on
+// MI355X (tools/microbench/light_loop.hip, trans_mix.hip): a plain f32 instruction costs ~2.4 SIMD
+// cycles per wavefront, a transcendental ~8 in a pure stream but 13-16 when mixed with plain ones, so
+// the five transcendentals are ~40 % of the loop; the kernel keeps the vector ALU busy ~100 % of the time.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -225,8 +228,8 @@ void vkr_launch_deferred_light(hipStream_t s, const LightArgs& a)
 	bool same = true;
 	for (int i = 1; i < VKR_NUM_LIGHTS_K; i++)
 		for (int c = 0; c < 3; c++) same = same && a.lightCol[i][c] == a.lightCol[0][c];
-	if (same) hipLaunchKernelGGL(k_deferred_light<true>, dim3((n + 255) / 256), dim3(256), 0, s, a);
-	else hipLaunchKernelGGL(k_deferred_light<false>, dim3((n + 255) / 256), dim3(256), 0, s, a);
+	if (same) hipLaunchKernelGGL((k_deferred_light<true>), dim3((n + 255) / 256), dim3(256), 0, s, a);
+	else hipLaunchKernelGGL((k_deferred_light<false>), dim3((n + 255) / 256), dim3(256), 0, s, a);
 }
 
 void vkr_launch_overvis_colour(hipStream_t s, const uint8_t* stencil, uint32_t* colour, const float* srgbThresh, uint32_t n)
