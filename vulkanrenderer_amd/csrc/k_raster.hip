@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 	const uint32_t n = end - beg;
 
 	for (uint32_t base = 0; base < n; base += 256) {
-		const uint32_t i = base + tid;
+		// entries are dealt to the four wavefronts round-robin, so a short bin still spreads its
+		// large (wave-cooperative) sub-triangles over all of them
+		const uint32_t i = base + (tid & 63u) * 4u + (tid >> 6);
 		bool has = i < n;
 		SubTri s;
 		int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
