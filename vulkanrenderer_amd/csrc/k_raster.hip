@@ -312,7 +312,7 @@ __global__ __launch_bounds__(1024) void k_raster_alpha(RasterArgs a)
 						t.t1 = make_float2(a.sc.uv[2 * (size_t)i1], a.sc.uv[2 * (size_t)i1 + 1]);
 						t.t2 = make_float2(a.sc.uv[2 * (size_t)i2], a.sc.uv[2 * (size_t)i2 + 1]);
 						const TexInfo& tex = a.sc.tex[a.sc.mat[a.sc.triMat[s.prim]].tex[3]];
-						t.off0 = tex.offset[0]; t.w0 = tex.w[0]; t.h0 = tex.h[0]; t.levels = tex.levels;
+						t.off0 = tex.alphaOff; t.w0 = tex.w[0]; t.h0 = tex.h[0]; t.levels = tex.levels;
 					}
 				}
 			}
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(1024) void k_raster_alpha(RasterArgs a)
 				float b[3], uv[2], d[4];
 				vkr_bary_at(pl, px, py, b);
 				vkr_uv_derivs(pl, px, py, b, t.t0, t.t1, t.t2, uv, d);
-				const float alpha = vkr_trilinear_alpha_wh(a.sc.texels, t.off0, t.w0, t.h0, t.levels, uv[0], uv[1], d);
+				const float alpha = vkr_trilinear_alpha_wh(a.sc.alphaTexels, t.off0, t.w0, t.h0, t.levels, uv[0], uv[1], d);
 				if (!(alpha < 0.5f)) {
 					const unsigned long long k2 = ((unsigned long long)f2u(z) << 32) | (unsigned long long)(0xFFFFFFFEu - c.prim);
 					if (k2 < key) { key = k2; upd = true; }

@@ -79,3 +79,19 @@ void vkr_launch_tbn_table(hipStream_t s, const uint32_t* tcomp, float4* out, uin
 	if (!nVert) return;
 	hipLaunchKernelGGL(k_tbn_table, dim3((nVert + 255) / 256), dim3(256), 0, s, tcomp, out, nVert);
 }
+
+// ---------------------------------------------------------------------------
+// Alpha bytes of one texture's whole mip chain (levels are stored back to
+// back), for the alpha test of the rasteriser.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_extract_alpha(const uint32_t* __restrict__ texels, uint8_t* __restrict__ out, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = (uint8_t)(texels[i] >> 24);
+}
+
+void vkr_launch_extract_alpha(hipStream_t s, const uint32_t* texels, uint8_t* out, uint32_t n)
+{
+	if (!n) return;
+	hipLaunchKernelGGL(k_extract_alpha, dim3((n + 255) / 256), dim3(256), 0, s, texels, out, n);
+}

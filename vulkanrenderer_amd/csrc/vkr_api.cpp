@@ -117,7 +117,7 @@ struct HostTex { uint32_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS], off[VKR_MAX_LEVE
 
 struct vkr_scene {
 	vkr_context* ctx = nullptr;
-	DevBuf pos, uv, tcomp, tbn, tri, triMat, orderB, tex, mat, texels;
+	DevBuf pos, uv, tcomp, tbn, tri, triMat, orderB, tex, mat, texels, alphaTexels;
 	SceneDev dev;
 	std::vector<HostTex> htex;
 	uint64_t nTri = 0, nVert = 0, texelCount = 0;
@@ -412,7 +412,7 @@ extern "C" void vkr_scene_destroy(vkr_scene* s)
 {
 	if (!s) return;
 	if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
-	DevBuf* bufs[] = { &s->pos, &s->uv, &s->tcomp, &s->tbn, &s->tri, &s->triMat, &s->orderB, &s->tex, &s->mat, &s->texels };
+	DevBuf* bufs[] = { &s->pos, &s->uv, &s->tcomp, &s->tbn, &s->tri, &s->triMat, &s->orderB, &s->tex, &s->mat, &s->texels, &s->alphaTexels };
 	for (DevBuf* b : bufs) b->release();
 	delete s;
 }
@@ -543,7 +543,7 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 			vkr_launch_mip_level(c->stream, s->texels.as<uint32_t>(), s->htex[i].off[l - 1], s->htex[i].w[l - 1], s->htex[i].h[l - 1],
 			                     s->htex[i].off[l], s->htex[i].w[l], s->htex[i].h[l], s->htex[i].srgb, c->dDecode, c->dThresh);
 	}
-	if ((rc = upload(s->tex, tinfo.data(), tinfo.size() * sizeof(TexInfo)))) return fail(rc);
+	for (auto& ti : tinfo) ti.alphaOff = 0xffffffffu;
 
 	// ---- materials: binding table + whether the alpha test can ever discard
 	std::vector<int> lowAlpha(d->textureCount, -1);
@@ -571,6 +571,26 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 		if (mi.alphaTest) s->anyAlphaTest = true;
 	}
 	if ((rc = upload(s->mat, minfo.data(), minfo.size() * sizeof(MatInfo)))) return fail(rc);
+	// ---- alpha byte pool: the chains of the textures an alpha test can sample
+	{
+		uint64_t bytes = 0;
+		for (uint32_t i = 0; i < d->materialCount; i++) {
+			if (!minfo[i].alphaTest) continue;
+			TexInfo& ti = tinfo[minfo[i].tex[3]];
+			if (ti.alphaOff != 0xffffffffu) continue;
+			const HostTex& h = s->htex[minfo[i].tex[3]];
+			ti.alphaOff = (uint32_t)bytes;
+			bytes += (uint64_t)h.off[h.levels - 1] + (uint64_t)h.w[h.levels - 1] * h.h[h.levels - 1] - h.off[0];
+		}
+		if ((rc = s->alphaTexels.ensure(bytes ? bytes : 4))) return fail(rc);
+		for (uint32_t t = 0; t < d->textureCount; t++) {
+			if (tinfo[t].alphaOff == 0xffffffffu) continue;
+			const HostTex& h = s->htex[t];
+			const uint32_t n = h.off[h.levels - 1] + h.w[h.levels - 1] * h.h[h.levels - 1] - h.off[0];
+			vkr_launch_extract_alpha(c->stream, s->texels.as<uint32_t>() + h.off[0], s->alphaTexels.as<uint8_t>() + tinfo[t].alphaOff, n);
+		}
+	}
+	if ((rc = upload(s->tex, tinfo.data(), tinfo.size() * sizeof(TexInfo)))) return fail(rc);
 	{
 		hipError_t e = hipStreamSynchronize(c->stream);
 		if (e != hipSuccess) return fail(set_error(VKR_E_DEVICE, "mip generation: %s", hipGetErrorString(e)));
@@ -578,7 +598,7 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 	SceneDev& dv = s->dev;
 	dv.pos = s->pos.as<float>(); dv.uv = s->uv.as<float>(); dv.tcomp = s->tcomp.as<uint32_t>(); dv.tbn = s->tbn.as<float4>();
 	dv.tri = s->tri.as<uint32_t>(); dv.triMat = s->triMat.as<uint32_t>(); dv.orderB = s->orderB.as<uint32_t>();
-	dv.tex = s->tex.as<TexInfo>(); dv.mat = s->mat.as<MatInfo>(); dv.texels = s->texels.as<uint32_t>();
+	dv.tex = s->tex.as<TexInfo>(); dv.mat = s->mat.as<MatInfo>(); dv.texels = s->texels.as<uint32_t>(); dv.alphaTexels = s->alphaTexels.as<uint8_t>();
 	dv.srgbDecode = c->dDecode; dv.srgbThresh = c->dThresh;
 	dv.nTri = (uint32_t)nTri; dv.nTriOpaque = (uint32_t)nTriOpaque; dv.nVert = (uint32_t)nVert;
 	dv.nTex = d->textureCount; dv.nMat = d->materialCount;

@@ -28,6 +28,7 @@ struct TexInfo {
 	uint16_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS];
 	int32_t levels;
 	int32_t srgb;
+	uint32_t alphaOff; // level-0 offset of this texture's chain in the alpha byte pool, ~0u if it has none
 };
 
 // Material -> the five bindings of the material descriptor set
@@ -61,6 +62,7 @@ struct SceneDev {
 	const TexInfo* tex;
 	const MatInfo* mat;
 	const uint32_t* texels;  // texel pool
+	const uint8_t* alphaTexels; // alpha bytes of the textures an alpha test samples, same level layout per chain
 	const float* srgbDecode; // 256
 	const float* srgbThresh; // 255
 	uint32_t nTri, nTriOpaque, nVert, nTex, nMat;
@@ -430,21 +432,29 @@ __device__ __forceinline__ void vkr_fetch(const SceneDev& sc, const TexInfo& t, 
 		if (MASK & (1 << c)) out[c] = vkr_lerp(a[c], b[c], tp.fr);
 }
 
-// .a of texture(sampler, uv) for a texture described by (off0, w0, h0, levels): the alpha test needs
-// nothing else, and with the level offsets recomputed the texel loads are the only memory round trip
-__device__ __forceinline__ float vkr_trilinear_alpha_wh(const uint32_t* __restrict__ texels, uint32_t off0, uint32_t w0, uint32_t h0,
+// .a of texture(sampler, uv) read from the alpha byte pool, for a texture described by (off0, w0, h0,
+// levels): the alpha test needs nothing else; bytes instead of RGBA texels keep a foliage texture's whole
+// chain inside L2, and with the level offsets recomputed the texel loads are the only memory round trip.
+// Same arithmetic as the .a component of vkr_fetch.
+__device__ __forceinline__ float vkr_bilinear_alpha8(const uint8_t* __restrict__ base, const LevelTaps& lt)
+{
+	const float a00 = vkr_unorm8(base[lt.i00]), a10 = vkr_unorm8(base[lt.i10]);
+	const float a01 = vkr_unorm8(base[lt.i01]), a11 = vkr_unorm8(base[lt.i11]);
+	return vkr_lerp(vkr_lerp(a00, a10, lt.fx), vkr_lerp(a01, a11, lt.fx), lt.fy);
+}
+
+__device__ __forceinline__ float vkr_trilinear_alpha_wh(const uint8_t* __restrict__ alphaTexels, uint32_t off0, uint32_t w0, uint32_t h0,
                                                         int levels, float u, float v, const float d[4])
 {
 	TexTaps tp;
 	vkr_make_taps_wh(w0, h0, levels, u, v, d, tp);
 	const uint32_t o0 = vkr_level_offset(off0, w0, h0, tp.lv);
-	float a[4], b[4];
-	vkr_bilinear_taps<8>(texels + o0, tp.t0, nullptr, a);
-	if (tp.fr == 0.0f) return a[3];
+	const float a = vkr_bilinear_alpha8(alphaTexels + o0, tp.t0);
+	if (tp.fr == 0.0f) return a;
 	uint32_t w = w0 >> tp.lv, h = h0 >> tp.lv;
 	const uint32_t o1 = o0 + (w ? w : 1u) * (h ? h : 1u);
-	vkr_bilinear_taps<8>(texels + o1, tp.t1, nullptr, b);
-	return vkr_lerp(a[3], b[3], tp.fr);
+	const float b = vkr_bilinear_alpha8(alphaTexels + o1, tp.t1);
+	return vkr_lerp(a, b, tp.fr);
 }
 
 // one-off trilinear fetch (all four channels)
