@@ -36,29 +36,11 @@ __device__ __forceinline__ float sat(float x) { return __builtin_amdgcn_fmed3f(x
 __device__ __forceinline__ float h2f_lo(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)); }
 __device__ __forceinline__ float h2f_hi(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); }
 
-// linear -> sRGB code with two LDS lookups: a hardware log2/exp2 estimate of
-// round(255*OETF(x)) corrected by at most one step against the exact
-// threshold table, so the result equals the table search of vkr_srgb_encode.
-// T points at 257 floats: T[0] = -inf, T[k+1] = threshold k, T[256] = +inf.
-__device__ __forceinline__ uint32_t srgb_encode_fast(const float* T, float x)
-{
-	x = fminf(fmaxf(x, 0.0f), 1.0f);
-	const float e = (x <= 0.0031308f) ? 12.92f * x
-	                                  : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)) - 0.055f;
-	int code = (int)(e * 255.0f + 0.5f);
-	code = min(max(code, 0), 255);
-	// code is right iff T[code] <= x < T[code+1]
-	if (x < T[code]) code--;
-	else if (x >= T[code + 1]) code++;
-	return (uint32_t)code;
-}
-
 template <bool SAMECOL>
 __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 {
 	__shared__ float sT[257];
-	if (threadIdx.x < 255) sT[threadIdx.x + 1] = a.srgbThresh[threadIdx.x];
-	if (threadIdx.x == 255) { sT[0] = -__builtin_inff(); sT[256] = __builtin_inff(); }
+	vkr_load_srgb_table(sT, a.srgbThresh);
 	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
 	const uint32_t n = rw * rh;
@@ -155,18 +137,28 @@ __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 		                          : (kdo[c] * S1[c] + f0[c] * S2[c] + omf0[c] * S3[c]);
 		acc[c] = 10.0f * lit + 0.03f * alb[c] * S0;
 	}
-	a.colour[p] = srgb_encode_fast(sT, acc[0]) | (srgb_encode_fast(sT, acc[1]) << 8) | (srgb_encode_fast(sT, acc[2]) << 16) |
-	              (vkr_unorm_encode(vkr_clamp01(S0)) << 24);
+	a.colour[p] = vkr_pack_colour_lds(sT, acc[0], acc[1], acc[2], S0);
 }
 
-// overVisRead.frag:7-13: oColor = (0,0.3,0,0.1) + vec4(vec3(stencil/25), 0)
+// overVisRead.frag:7-13: oColor = (0,0.3,0,0.1) + vec4(vec3(stencil/25), 0).  The colour depends on the
+// 8-bit counter only: each workgroup builds the 256-entry table once, pixels are lookups.
 __global__ __launch_bounds__(256) void k_overvis_colour(const uint8_t* __restrict__ stencil, uint32_t* __restrict__ colour,
                                                          const float* __restrict__ thresh, uint32_t n)
 {
-	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-	if (p >= n) return;
-	float s = (float)stencil[p] / 25.0f;
-	colour[p] = vkr_pack_colour(thresh, 0.0f + s, 0.3f + s, 0.0f + s, 0.1f);
+	__shared__ uint32_t lut[256];
+	{
+		const float s = (float)threadIdx.x / 25.0f;
+		lut[threadIdx.x] = vkr_pack_colour(thresh, 0.0f + s, 0.3f + s, 0.0f + s, 0.1f);
+	}
+	__syncthreads();
+	// four pixels per thread
+	const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+	if (p + 3 < n && ((size_t)stencil & 3u) == 0 && ((size_t)colour & 15u) == 0) {
+		const uint32_t s4 = *(const uint32_t*)(stencil + p);
+		*(uint4*)(colour + p) = make_uint4(lut[s4 & 255u], lut[(s4 >> 8) & 255u], lut[(s4 >> 16) & 255u], lut[s4 >> 24]);
+	} else {
+		for (uint32_t k = p; k < n && k < p + 4; k++) colour[k] = lut[stencil[k]];
+	}
 }
 
 // postProcess.frag:9-25 sampling the offscreen R8G8B8A8_SRGB image
@@ -176,6 +168,11 @@ __global__ __launch_bounds__(256) void k_mosaic(const uint32_t* __restrict__ src
                                                  uint32_t srcH, uint32_t* __restrict__ dst, ViewDev view,
                                                  const float* __restrict__ decode, const float* __restrict__ thresh)
 {
+	__shared__ float sT[257];
+	__shared__ float sDec[256];
+	vkr_load_srgb_table(sT, thresh);
+	sDec[threadIdx.x] = decode[threadIdx.x];
+	__syncthreads();
 	const uint32_t rw = view.x1 - view.x0, rh = view.y1 - view.y0;
 	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
 	if (x >= rw || y >= rh) return;
@@ -203,15 +200,15 @@ __global__ __launch_bounds__(256) void k_mosaic(const uint32_t* __restrict__ src
 		const uint32_t sh = 8u * k;
 		float a00, a10, a01, a11;
 		if (k < 3) {
-			a00 = decode[(t00 >> sh) & 0xffu]; a10 = decode[(t10 >> sh) & 0xffu];
-			a01 = decode[(t01 >> sh) & 0xffu]; a11 = decode[(t11 >> sh) & 0xffu];
+			a00 = sDec[(t00 >> sh) & 0xffu]; a10 = sDec[(t10 >> sh) & 0xffu];
+			a01 = sDec[(t01 >> sh) & 0xffu]; a11 = sDec[(t11 >> sh) & 0xffu];
 		} else {
-			a00 = (float)(t00 >> 24) / 255.0f; a10 = (float)(t10 >> 24) / 255.0f;
-			a01 = (float)(t01 >> 24) / 255.0f; a11 = (float)(t11 >> 24) / 255.0f;
+			a00 = vkr_unorm8(t00 >> 24); a10 = vkr_unorm8(t10 >> 24);
+			a01 = vkr_unorm8(t01 >> 24); a11 = vkr_unorm8(t11 >> 24);
 		}
 		c[k] = vkr_lerp(vkr_lerp(a00, a10, fx), vkr_lerp(a01, a11, fx), fy);
 	}
-	dst[(size_t)y * rw + x] = vkr_pack_colour(thresh, c[0], c[1], c[2], c[3]);
+	dst[(size_t)y * rw + x] = vkr_pack_colour_lds(sT, c[0], c[1], c[2], c[3]);
 }
 
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* dst, uint32_t value, size_t n)
@@ -235,7 +232,7 @@ void vkr_launch_deferred_light(hipStream_t s, const LightArgs& a)
 void vkr_launch_overvis_colour(hipStream_t s, const uint8_t* stencil, uint32_t* colour, const float* srgbThresh, uint32_t n)
 {
 	if (!n) return;
-	hipLaunchKernelGGL(k_overvis_colour, dim3((n + 255) / 256), dim3(256), 0, s, stencil, colour, srgbThresh, n);
+	hipLaunchKernelGGL(k_overvis_colour, dim3((n + 1023) / 1024), dim3(256), 0, s, stencil, colour, srgbThresh, n);
 }
 
 void vkr_launch_mosaic(hipStream_t s, const uint32_t* src, uint32_t srcX0, uint32_t srcY0, uint32_t srcW, uint32_t srcH,

@@ -365,61 +365,76 @@ __global__ __launch_bounds__(1024) void k_raster_alpha(RasterArgs a)
 // ---------------------------------------------------------------------------
 // Overshading counter (debug view 6): stencil increments only for fragments
 // that pass LESS_OR_EQUAL against the depth written so far, in submission
-// order (main/main.cpp:2781-2797, 4122-4123).  Order matters, so each thread
-// owns four pixels and walks the tile's bin, sorted by primitive, staged
-// through LDS 256 sub-triangles at a time.
+// order (main/main.cpp:2781-2797, 4122-4123).  Order matters, so the kernel is
+// pixel-owner like k_raster_alpha: one 1024-thread workgroup per tile, a
+// wavefront per 8x8 block, a lane per pixel holding its depth and counter in
+// registers, walking the tile's bin - sorted by primitive - staged through LDS
+// 256 entries at a time with the edge functions set up once per entry.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_overshade(OvershadeArgs a)
+__global__ __launch_bounds__(1024) void k_overshade(OvershadeArgs a)
 {
-	__shared__ SubTri q[256];
+	__shared__ AlphaCover sCov[ALPHA_CHUNK];
 	const uint32_t tile = blockIdx.x;
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
 	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = (int)(a.view.y0 + ty * VKR_TILE);
 	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = min(oy + VKR_TILE, (int)a.view.y1) - 1;
-	const uint32_t tid = threadIdx.x;
-	// thread -> pixels (x, y + 8*k), k = 0..3
-	const int lx = (int)(tid & 31), ly = (int)(tid >> 5);
-	float depth[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
-	uint32_t cnt[4] = { 0, 0, 0, 0 };
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const int bxl = (int)(wid & 3) * 8, byl = (int)(wid >> 2) * 8;
+	const int lx = bxl + (int)(lane & 7), ly = byl + (int)(lane >> 3);
+	const int px = ox + lx, py = oy + ly;
+	const bool inRect = px <= ex && py <= ey;
+	const double dlx = (double)lx, dly = (double)ly;
+	float depth = 1.0f;
+	uint32_t cnt = 0;
 
 	uint32_t beg = a.tileOffset[tile], end = a.tileOffset[tile + 1];
 	if (end > a.binCap) end = a.binCap;
 	if (beg > end) beg = end;
 	const uint32_t n = end - beg;
-	for (uint32_t base = 0; base < n; base += 256) {
+	for (uint32_t base = 0; base < n; base += ALPHA_CHUNK) {
 		__syncthreads();
-		if (base + tid < n) q[tid] = a.recs[a.binList[beg + base + tid]];
-		__syncthreads();
-		const uint32_t m = min(256u, n - base);
-		for (uint32_t j = 0; j < m; j++) {
-			const SubTri& s = q[j];
+		if (tid < ALPHA_CHUNK && base + tid < n) {
+			const SubTri s = a.recs[a.binList[beg + base + tid]];
+			AlphaCover& c = sCov[tid];
 			int bx0, by0, bx1, by1;
 			tri_bbox(s, bx0, by0, bx1, by1);
-			const int px = ox + lx;
-			if (px < bx0 || px > bx1) continue;
-#pragma unroll
-			for (int k = 0; k < 4; k++) {
-				const int py = oy + ly + 8 * k;
-				if (py < by0 || py > by1 || px > ex || py > ey) continue;
+			bx0 = max(bx0, ox); by0 = max(by0, oy); bx1 = min(bx1, ex); by1 = min(by1, ey);
+			if (bx0 <= bx1 && by0 <= by1) {
 				EdgeSetup E;
-				edge_setup(s, px, py, E);
-				if (!edges_inside(E.e0, E.e1, E.e2)) continue;
-				float z = vkr_depth_at(s.Az, s.Bz, s.Cz, px, py);
-				if (!(z >= 0.0f && z <= 1.0f)) continue;
-				if (!(z <= depth[k])) continue;
-				depth[k] = z;
-				if (cnt[k] < 255u) cnt[k]++;
+				edge_setup(s, ox, oy, E);
+				c.e0 = E.e0; c.e1 = E.e1; c.e2 = E.e2;
+				c.sx0 = E.sx0; c.sx1 = E.sx1; c.sx2 = E.sx2;
+				c.sy0 = E.sy0; c.sy1 = E.sy1; c.sy2 = E.sy2;
+				c.Az = s.Az; c.Bz = s.Bz; c.Cz = s.Cz;
+				c.prim = s.prim;
+				c.bbox = (uint32_t)(bx0 - ox) | ((uint32_t)(by0 - oy) << 8) | ((uint32_t)(bx1 - ox) << 16) | ((uint32_t)(by1 - oy) << 24);
+			} else {
+				c.bbox = 0x0000ffffu; // x0 = y0 = 255 > x1 = y1 = 0: misses every block
 			}
 		}
+		__syncthreads();
+		const uint32_t m = min((uint32_t)ALPHA_CHUNK, n - base);
+		for (uint32_t j = 0; j < m; j++) {
+			const AlphaCover& c = sCov[j];
+			const uint32_t bb = c.bbox;
+			const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
+			if (x1 < bxl || x0 > bxl + 7 || y1 < byl || y0 > byl + 7) continue; // misses the block (wave-uniform)
+			const double e0 = fma(c.sy0, dly, fma(c.sx0, dlx, c.e0));
+			const double e1 = fma(c.sy1, dly, fma(c.sx1, dlx, c.e1));
+			const double e2 = fma(c.sy2, dly, fma(c.sx2, dlx, c.e2));
+			if (!(inRect && lx >= x0 && lx <= x1 && ly >= y0 && ly <= y1 && edges_inside(e0, e1, e2))) continue;
+			const float z = vkr_depth_at(c.Az, c.Bz, c.Cz, px, py);
+			if (!(z >= 0.0f && z <= 1.0f)) continue;
+			if (!(z <= depth)) continue;
+			depth = z;
+			if (cnt < 255u) cnt++;
+		}
 	}
-	const uint32_t rw = a.view.x1 - a.view.x0;
-#pragma unroll
-	for (int k = 0; k < 4; k++) {
-		const int px = ox + lx, py = oy + ly + 8 * k;
-		if (px > ex || py > ey) continue;
+	if (inRect) {
+		const uint32_t rw = a.view.x1 - a.view.x0;
 		const size_t p = (size_t)(py - (int)a.view.y0) * rw + (size_t)(px - (int)a.view.x0);
-		a.countOut[p] = (uint8_t)cnt[k];
-		if (a.depthOut) a.depthOut[p] = depth[k];
+		a.countOut[p] = (uint8_t)cnt;
+		if (a.depthOut) a.depthOut[p] = depth;
 	}
 }
 
@@ -439,5 +454,5 @@ void vkr_launch_overshade(hipStream_t s, const OvershadeArgs& a)
 {
 	const uint32_t nTiles = a.view.tilesX * a.view.tilesY;
 	if (!nTiles) return;
-	hipLaunchKernelGGL(k_overshade, dim3(nTiles), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_overshade, dim3(nTiles), dim3(1024), 0, s, a);
 }

@@ -150,19 +150,21 @@ __device__ __forceinline__ void brdf_forward(const float L[3], const float V[3],
 	float vdh = vkr_dot3(V[0], V[1], V[2], Hh[0], Hh[1], Hh[2]);
 	float nh = fmaxf(ndh, 0.0001f);
 	float nh2 = nh * nh, nh4 = nh2 * nh2, r2 = rough * rough;
-	float ndf = expf((nh2 - 1.0f) / (r2 * nh2)) / (0.001f + PI * r2 * nh4);
+	// colour only: hardware reciprocal and exp2
+	float ndf = __builtin_amdgcn_exp2f((nh2 - 1.0f) * 1.4426950408889634f * __builtin_amdgcn_rcpf(r2 * nh2)) * __builtin_amdgcn_rcpf(0.001f + PI * r2 * nh4);
 	float x = 1.0f - vdh;
 	float x2 = x * x, x5 = x2 * x2 * x;
-	float tl = 2.0f * (fmaxf(0.0f, ndh) * fmaxf(0.0f, ndv) / vdh);
-	float tr = 2.0f * (fmaxf(0.0f, ndh) * fmaxf(0.0f, ndl) / vdh);
+	const float rvdh = __builtin_amdgcn_rcpf(vdh);
+	float tl = 2.0f * (fmaxf(0.0f, ndh) * fmaxf(0.0f, ndv) * rvdh);
+	float tr = 2.0f * (fmaxf(0.0f, ndh) * fmaxf(0.0f, ndl) * rvdh);
 	float G = fminf(1.0f, fminf(tl, tr));
-	float denom = 0.001f + 4.0f * fmaxf(ndv, 0.0f) * fmaxf(ndl, 0.0f);
+	float rdenom = __builtin_amdgcn_rcpf(0.001f + 4.0f * fmaxf(ndv, 0.0f) * fmaxf(ndl, 0.0f));
 #pragma unroll
 	for (int i = 0; i < 3; i++) {
 		float f0 = (1.0f - metal) * 0.04f + metal * albedo[i];
 		float F = f0 + (1.0f - f0) * x5;
-		float diffuse = (albedo[i] / PI) * (1.0f - F) * (1.0f - metal);
-		out[i] = diffuse + (ndf * F * G) / denom;
+		float diffuse = (albedo[i] * (1.0f / PI)) * (1.0f - F) * (1.0f - metal);
+		out[i] = diffuse + (ndf * F * G) * rdenom;
 	}
 }
 
@@ -187,7 +189,9 @@ __device__ __forceinline__ float shadow_lookup(const float* sm, int S, float u, 
 __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 {
 	__shared__ float sDec[256];
+	__shared__ float sT[257];
 	sDec[threadIdx.x] = a.sc.srgbDecode[threadIdx.x];
+	vkr_load_srgb_table(sT, a.sc.srgbThresh);
 	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
 	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 	if (a.depth) a.depth[p] = depth;
 	if (a.triId) a.triId[p] = prim;
 	// clear colour (0.1,0.1,0.1,1), main/main.cpp:3988-3991
-	uint32_t colour = vkr_pack_colour(a.sc.srgbThresh, 0.1f, 0.1f, 0.1f, 1.0f);
+	uint32_t colour = vkr_pack_colour_lds(sT, 0.1f, 0.1f, 0.1f, 1.0f);
 	Frag f;
 	if (prim != VKR_NO_PRIM && load_frag<false>(a, px, py, prim, f)) {
 		MatSample ms;
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 			float lit = (br[i] * 100.0f) * a.lightColour[i] * ndl;
 			c[i] = ambient + (lit * sh) * att;
 		}
-		colour = vkr_pack_colour(a.sc.srgbThresh, c[0], c[1], c[2], 1.0f);
+		colour = vkr_pack_colour_lds(sT, c[0], c[1], c[2], 1.0f);
 	}
 	a.colour[p] = colour;
 }
@@ -243,6 +247,9 @@ __device__ __forceinline__ float linearise_depth(float d)
 
 __global__ __launch_bounds__(256) void k_resolve_debug(ResolveArgs a)
 {
+	__shared__ float sT[257];
+	vkr_load_srgb_table(sT, a.sc.srgbThresh);
+	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
 	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
 	if (x >= rw || y >= rh) return;
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256) void k_resolve_debug(ResolveArgs a)
 	decode_key(a.vis[p], depth, prim);
 	if (a.depth) a.depth[p] = depth;
 	if (a.triId) a.triId[p] = prim;
-	uint32_t colour = vkr_pack_colour(a.sc.srgbThresh, 0.1f, 0.1f, 0.1f, 1.0f); // main/main.cpp:4139-4143
+	uint32_t colour = vkr_pack_colour_lds(sT, 0.1f, 0.1f, 0.1f, 1.0f); // main/main.cpp:4139-4143
 	uint8_t mip = 0xff;
 	if (prim != VKR_NO_PRIM) {
 		// passes in file order carry the file-order rank; map back to the order-A triangle
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(256) void k_resolve_debug(ResolveArgs a)
 					vkr_trilinear(a.sc, t, f.uv[0], f.uv[1], f.d, c);
 				}
 			}
-			colour = vkr_pack_colour(a.sc.srgbThresh, c[0], c[1], c[2], c[3]);
+			colour = vkr_pack_colour_lds(sT, c[0], c[1], c[2], c[3]);
 		}
 	}
 	a.colour[p] = colour;

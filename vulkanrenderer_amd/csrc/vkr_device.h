@@ -180,6 +180,34 @@ __device__ __forceinline__ uint32_t vkr_pack_colour(const float* thresh, float r
 	       (vkr_srgb_encode(thresh, vkr_clamp01(b)) << 16) | (vkr_unorm_encode(vkr_clamp01(a)) << 24);
 }
 
+// ---- sRGB encode through an LDS copy of the threshold table -------------------------------------------
+// T holds 257 floats: T[0] = -inf, T[k+1] = threshold k, T[256] = +inf.  A hardware log2/exp2 estimate of
+// round(255*OETF(x)) is corrected by at most one step against the exact thresholds, so the result equals
+// the table search of vkr_srgb_encode for every x.
+__device__ __forceinline__ void vkr_load_srgb_table(float* T, const float* __restrict__ thresh)
+{
+	for (uint32_t i = threadIdx.x; i < 257u; i += blockDim.x)
+		T[i] = (i == 0) ? -__builtin_inff() : (i == 256) ? __builtin_inff() : thresh[i - 1];
+}
+
+__device__ __forceinline__ uint32_t vkr_srgb_encode_lds(const float* T, float x)
+{
+	x = fminf(fmaxf(x, 0.0f), 1.0f); // NaN -> 0, as vkr_srgb_encode
+	const float e = (x <= 0.0031308f) ? 12.92f * x
+	                                  : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)) - 0.055f;
+	int code = (int)(e * 255.0f + 0.5f);
+	code = min(max(code, 0), 255);
+	if (x < T[code]) code--;             // code is right iff T[code] <= x < T[code+1]
+	else if (x >= T[code + 1]) code++;
+	return (uint32_t)code;
+}
+
+__device__ __forceinline__ uint32_t vkr_pack_colour_lds(const float* T, float r, float g, float b, float a)
+{
+	return vkr_srgb_encode_lds(T, r) | (vkr_srgb_encode_lds(T, g) << 8) | (vkr_srgb_encode_lds(T, b) << 16) |
+	       (vkr_unorm_encode(vkr_clamp01(a)) << 24);
+}
+
 __device__ __forceinline__ float vkr_lerp(float a, float b, float t) { return fmaf(t, b - a, a); }
 __device__ __forceinline__ float vkr_dot3(float ax, float ay, float az, float bx, float by, float bz)
 {
