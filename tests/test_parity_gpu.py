@@ -71,6 +71,42 @@ def test_micro_scene_modes(gpu, micro_oracle, mode, pose):
     compare(ref, got, mode)
 
 
+def test_odd_texture_sizes():
+    """Non-power-of-two textures whose sizes differ inside a material: the general REPEAT wrap and the
+    per-texture footprint rebuild, against the oracle."""
+    from oracle import oracle
+    from vulkanrenderer_amd import abi, renderer, scenes
+    packed = scenes.micro_scene(odd_textures=True)
+    osc = oracle.OracleScene(packed)
+    ctx = renderer.Context(0)
+    sc = renderer.Scene(ctx, packed)
+    try:
+        W, H = 160, 90
+        for mode in ("deferred", "forward", "mip", "albedo"):
+            kw = MODES[mode]
+            for pose in ("p1", "back"):
+                u = renderer.make_uniforms(W, H, POSES[pose], kw.get("debug", 1))
+                p = abi.make_params(W, H, u, shadow_size=256, **kw)
+                compare(osc.render(p), sc.render(p), mode + "/odd/" + pose if mode != "deferred" else "deferred")
+    finally:
+        sc.close(); ctx.close(); osc.close()
+
+
+def test_lights_of_different_colours(gpu, micro_oracle):
+    """The deferred kernel has a fast path for 21 lights of one colour (the reference's braziers); this
+    exercises the general path."""
+    from vulkanrenderer_amd import abi, renderer
+    ctx, sc = gpu
+    W, H = 160, 90
+    u = renderer.make_uniforms(W, H, POSES["p1"], 1)
+    rng = np.random.default_rng(5)
+    for i in range(21):
+        for c in range(3):
+            u.multipleLightsUniform.light[i].lightColour[c] = float(rng.random())
+    p = abi.make_params(W, H, u, deferred=True)
+    compare(micro_oracle.render(p), sc.render(p), "deferred")
+
+
 def test_rect_equals_crop(gpu):
     """Sort-first: a sub-rectangle rendered alone equals the crop of the full frame."""
     from vulkanrenderer_amd import abi, renderer

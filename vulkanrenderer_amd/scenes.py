@@ -208,7 +208,10 @@ def foliage_cluster(rng, center, count, size, material, spread=0.8):
 # --------------------------------------------------------------------------
 # scenes
 # --------------------------------------------------------------------------
-def micro_scene(tex_size=16, seed=7):
+ODD_SIZES = [(24, 20), (17, 9), (5, 7), (16, 16), (12, 10), (31, 13), (3, 32), (1, 6)]
+
+
+def micro_scene(tex_size=16, seed=7, odd_textures=False):
     """A few dozen triangles with every feature the parity tests need: a floor
     that passes under the camera (near-plane clipping), a tiled back wall
     (minification), a column, a sphere, two alpha-masked double-sided quads,
@@ -229,6 +232,13 @@ def micro_scene(tex_size=16, seed=7):
     meshes.append(sphere_bowl((0.6, -0.9, -3.5), 0.6, 10, 6, m_metal))
     # a coplanar duplicate of part of the floor: equal-depth fragments, later primitive must win
     meshes.append(grid_surface((-1, -1.5, -2), (2, 0, 0), (0, 0, -2), 1, 1, (0, 0), (1, 0), (0, 1), m_wall))
+    if odd_textures:
+        # non-power-of-two sizes, different for every texture of a material (crops of the generated ones)
+        for i, t in enumerate(textures):
+            h, w = ODD_SIZES[i % len(ODD_SIZES)]
+            src = t["rgba8"]
+            reps = (-(-h // src.shape[0]), -(-w // src.shape[1]), 1)
+            t["rgba8"] = np.ascontiguousarray(np.tile(src, reps)[:h, :w])
     return PackedScene(textures, materials, meshes)
 
 
