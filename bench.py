@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs, collectives on host tensors)")
     ap.add_argument("--profile-all", action="store_true", help="time every stage with HIP events (adds host overhead)")
     args = ap.parse_args()
 
@@ -84,7 +86,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+            local_rank %= max(1, torch.cuda.device_count())
     if world != args.gpus:
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
@@ -108,7 +114,7 @@ def main():
     sortfirst = args.partition == "sortfirst" and world > 1
     comp = None
     if sortfirst:
-        comp = BandCompositor(W, H, dev, rank, world)
+        comp = BandCompositor(W, H, dev, rank, world, host_collective=(args.backend == "gloo"))
         rect = comp.rect
         out_t = comp.local
     else:
@@ -148,7 +154,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     report = ctx.profile_report()

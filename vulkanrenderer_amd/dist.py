@@ -31,7 +31,10 @@ def pose_indices(rank, world, n_poses):
 class BandCompositor:
     """Gathers the per-rank RGBA8 bands of one frame into the full image on rank 0."""
 
-    def __init__(self, width, height, device, rank=None, world=None):
+    def __init__(self, width, height, device, rank=None, world=None, host_collective=False):
+        """host_collective: gather through host tensors (gloo rehearsals); the product path gathers device
+        tensors over RCCL."""
+        self.host = host_collective
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
         self.width, self.height = width, height
@@ -40,7 +43,9 @@ class BandCompositor:
         # every rank contributes a buffer of the tallest band (gather needs equal sizes); short bands are padded
         self.band_h = max(r[3] - r[1] for r in self.rects)
         self.local = torch.zeros((self.band_h, width, 4), dtype=torch.uint8, device=device)
-        self.gathered = ([torch.empty_like(self.local) for _ in range(self.world)] if self.rank == 0 else None)
+        gdev = "cpu" if host_collective else device
+        self.gathered = ([torch.empty(self.local.shape, dtype=torch.uint8, device=gdev) for _ in range(self.world)]
+                         if self.rank == 0 else None)
 
     @property
     def rect(self):
@@ -50,7 +55,7 @@ class BandCompositor:
         """Returns the H x W x 4 frame on rank 0, None elsewhere."""
         if self.world == 1:
             return self.local[: self.height]
-        dist.gather(self.local, self.gathered, dst=0)
+        dist.gather(self.local.cpu() if self.host else self.local, self.gathered, dst=0)
         if self.rank != 0:
             return None
         rows = [g[: r[3] - r[1]] for g, r in zip(self.gathered, self.rects) if r[3] > r[1]]
