@@ -159,16 +159,28 @@ __device__ __forceinline__ bool prepare_subtri(const SetupArgs& a, int32_t X0, i
 	return true;
 }
 
-// countTiles = false leaves the per-tile counting to the caller
-__device__ __forceinline__ bool commit_subtri(const SetupArgs& a, uint32_t slot, const SubTri& r, uint2 tiles, bool countTiles = true)
+// Tile counting with the position kept: a record that touches at most 8 tiles
+// remembers, per tile, the value the counter had (its index inside the tile's
+// bin), so the fill pass needs no second round of atomics for it.  Records that
+// touch more tiles are counted separately and take their positions, behind the
+// others, from a cursor in the fill pass.
+__device__ __forceinline__ void count_small(const SetupArgs& a, uint32_t slot, uint2 tiles)
+{
+	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
+	uint32_t k = 0;
+	for (uint32_t ty = ty0; ty <= ty1; ty++)
+		for (uint32_t tx = tx0; tx <= tx1; tx++, k++) a.recLocal[(size_t)slot * 8 + k] = atomicAdd(&a.tileCount[ty * a.view.tilesX + tx], 1u);
+}
+
+__device__ __forceinline__ bool commit_subtri(const SetupArgs& a, uint32_t slot, const SubTri& r, uint2 tiles)
 {
 	if (slot >= a.recCap) { atomicOr(a.overflow, 1u); return false; }
 	a.recs[slot] = r;
 	a.recTiles[slot] = tiles;
-	if (!countTiles) return true;
 	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
+	if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 8) { count_small(a, slot, tiles); return true; }
 	for (uint32_t ty = ty0; ty <= ty1; ty++)
-		for (uint32_t tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tileCount[ty * a.view.tilesX + tx], 1u);
+		for (uint32_t tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tileCountBig[ty * a.view.tilesX + tx], 1u);
 	return true;
 }
 
@@ -289,11 +301,12 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 	}
 	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
 	const uint32_t nt = emit ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0u;
-	// one-tile records: grouped by tile inside the wave
-	wave_tile_add<false>(a.tileCount, ty0 * a.view.tilesX + tx0, nt == 1);
-	if (nt > 1 && nt <= 8)
-		for (uint32_t ty = ty0; ty <= ty1; ty++)
-			for (uint32_t tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tileCount[ty * a.view.tilesX + tx], 1u);
+	// one-tile records: grouped by tile inside the wave; the value returned is the record's index in the tile's bin
+	{
+		const uint32_t local = wave_tile_add<true>(a.tileCount, ty0 * a.view.tilesX + tx0, nt == 1);
+		if (nt == 1) a.recLocal[(size_t)slot * 8] = local;
+	}
+	if (nt > 1 && nt <= 8) count_small(a, slot, tiles);
 	// records that touch many tiles: the wave counts them together
 	unsigned long long bmask = __ballot(nt > 8);
 	while (bmask) {
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 		const uint32_t wx0 = __shfl(tx0, src, 64), wy0 = __shfl(ty0, src, 64);
 		const uint32_t wx1 = __shfl(tx1, src, 64), wy1 = __shfl(ty1, src, 64);
 		const uint32_t w = wx1 - wx0 + 1, cnt = w * (wy1 - wy0 + 1);
-		for (uint32_t k = lane; k < cnt; k += 64) atomicAdd(&a.tileCount[(wy0 + k / w) * a.view.tilesX + (wx0 + k % w)], 1u);
+		for (uint32_t k = lane; k < cnt; k += 64) atomicAdd(&a.tileCountBig[(wy0 + k / w) * a.view.tilesX + (wx0 + k % w)], 1u);
 	}
 }
 
@@ -322,9 +335,9 @@ __global__ __launch_bounds__(64) void k_setup_clip(SetupArgs a)
 // ---------------------------------------------------------------------------
 // exclusive scan of the per-tile counts (one workgroup), cursor reset
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ count, uint32_t* __restrict__ offset,
-                                                      uint32_t* __restrict__ cursor, uint32_t nTiles, uint32_t cap,
-                                                      uint32_t* overflow)
+__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ count, const uint32_t* __restrict__ countBig,
+                                                      uint32_t* __restrict__ offset, uint32_t* __restrict__ cursor, uint32_t nTiles,
+                                                      uint32_t cap, uint32_t* overflow)
 {
 	__shared__ uint32_t wsum[16];
 	__shared__ uint32_t carry;
@@ -333,7 +346,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 	__syncthreads();
 	for (uint32_t base = 0; base < nTiles; base += 1024) {
 		uint32_t i = base + tid;
-		uint32_t v = (i < nTiles) ? count[i] : 0u;
+		uint32_t v = (i < nTiles) ? count[i] + countBig[i] : 0u;
 		uint32_t s = v; // inclusive scan in the wave
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
@@ -373,23 +386,13 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 	}
 	const uint32_t nt = has ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0;
 	const bool big = nt > 8;
-	{
-		// one-tile records: one atomic per group of lanes that share the tile
-		const uint32_t tile = ty0 * a.tilesX + tx0;
-		const uint32_t local = wave_tile_add<true>(a.cursor, tile, nt == 1);
-		if (nt == 1) {
-			const uint32_t idx = a.tileOffset[tile] + local;
-			if (idx < a.binCap) {
-				a.binList[idx] = r;
-				if (a.keys) a.keys[idx] = key;
-			}
-		}
-	}
-	if (has && !big && nt > 1) {
+	if (has && !big) {
+		// positions were fixed by the counting pass
+		uint32_t k = 0;
 		for (uint32_t ty = ty0; ty <= ty1; ty++)
-			for (uint32_t tx = tx0; tx <= tx1; tx++) {
+			for (uint32_t tx = tx0; tx <= tx1; tx++, k++) {
 				const uint32_t tile = ty * a.tilesX + tx;
-				const uint32_t idx = a.tileOffset[tile] + atomicAdd(&a.cursor[tile], 1u);
+				const uint32_t idx = a.tileOffset[tile] + a.recLocal[(size_t)r * 8 + k];
 				if (idx < a.binCap) {
 					a.binList[idx] = r;
 					if (a.keys) a.keys[idx] = key;
@@ -407,7 +410,8 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 		const uint32_t w = wx1 - wx0 + 1, cnt = w * (wy1 - wy0 + 1);
 		for (uint32_t k = lane; k < cnt; k += 64) {
 			const uint32_t tile = (wy0 + k / w) * a.tilesX + (wx0 + k % w);
-			const uint32_t idx = a.tileOffset[tile] + atomicAdd(&a.cursor[tile], 1u);
+			// behind the entries of the records whose positions the counting pass fixed
+			const uint32_t idx = a.tileOffset[tile] + a.tileCount[tile] + atomicAdd(&a.cursor[tile], 1u);
 			if (idx < a.binCap) {
 				a.binList[idx] = wr;
 				if (a.keys) a.keys[idx] = wkey;
@@ -431,10 +435,10 @@ void vkr_launch_setup(hipStream_t s, const SetupArgs& a)
 	hipLaunchKernelGGL(k_setup_clip, dim3(512), dim3(64), 0, s, a);
 }
 
-void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, uint32_t* offset, uint32_t* cursor, uint32_t nTiles,
-                           uint32_t cap, uint32_t* overflow)
+void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
+                           uint32_t nTiles, uint32_t cap, uint32_t* overflow)
 {
-	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, count, offset, cursor, nTiles, cap, overflow);
+	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, count, countBig, offset, cursor, nTiles, cap, overflow);
 }
 
 void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs)
