@@ -259,6 +259,8 @@ __global__ __launch_bounds__(1024) void k_raster_alpha(RasterArgs a)
 	__shared__ AlphaCover sCov[ALPHA_CHUNK];
 	__shared__ AlphaAttr sAttr[ALPHA_CHUNK];
 	__shared__ uint32_t sCount;
+	__shared__ uint32_t sZKey[ALPHA_CHUNK];  // depth of the entry's plane at the tile centre
+	__shared__ uint16_t sOrder[ALPHA_CHUNK]; // staged entries, nearest first
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
 	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = (int)(a.view.y0 + ty * VKR_TILE);
 	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = min(oy + VKR_TILE, (int)a.view.y1) - 1;
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(1024) void k_raster_alpha(RasterArgs a)
 						c.Az = s.Az; c.Bz = s.Bz; c.Cz = s.Cz;
 						c.prim = s.prim;
 						c.bbox = (uint32_t)(bx0 - ox) | ((uint32_t)(by0 - oy) << 8) | ((uint32_t)(bx1 - ox) << 16) | ((uint32_t)(by1 - oy) << 24);
+						sZKey[slot] = f2u(fminf(fmaxf(vkr_depth_at(s.Az, s.Bz, s.Cz, ox + VKR_TILE / 2, oy + VKR_TILE / 2), 0.0f), 1.0f));
 						AlphaAttr& t = sAttr[slot];
 #pragma unroll
 						for (int k = 0; k < 3; k++) { t.a[k] = pl.a[k]; t.b[k] = pl.b[k]; t.c[k] = pl.c[k]; }
@@ -319,7 +322,21 @@ __global__ __launch_bounds__(1024) void k_raster_alpha(RasterArgs a)
 		}
 		__syncthreads();
 		const uint32_t m = sCount;
-		for (uint32_t j = 0; j < m; j++) {
+		// Near entries first, so that what lies behind them fails the depth test before its alpha test: each
+		// staged entry finds its rank by counting the entries in front of it.  The order changes the work, not
+		// the result.
+		if (tid < m) {
+			const uint32_t mine = sZKey[tid];
+			uint32_t rank = 0;
+			for (uint32_t k = 0; k < m; k++) {
+				const uint32_t other = sZKey[k];
+				rank += (other < mine || (other == mine && k < tid)) ? 1u : 0u;
+			}
+			sOrder[rank] = (uint16_t)tid;
+		}
+		__syncthreads();
+		for (uint32_t jj = 0; jj < m; jj++) {
+			const uint32_t j = sOrder[jj];
 			const AlphaCover& c = sCov[j];
 			const uint32_t bb = c.bbox;
 			const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
