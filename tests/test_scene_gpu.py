@@ -186,3 +186,29 @@ def test_properties_at_full_resolution(ctx):
     blocks = mo.reshape(360, 3, 384, 5, 4)
     assert np.all(blocks == blocks[:, :1, :, :1, :])                                            # 5x3 blocks are flat
     sc.close()
+
+
+def test_full_scene_1080p_against_oracle(ctx):
+    """The benchmark's own workload - every triangle of the SunTemple-proxy (smaller textures), fly-through poses of
+    bench.py - at 1920x1080 against the oracle: integer buffers bit-exact, colour within 1/255."""
+    from bench import fly_pose
+    from oracle import oracle
+    from vulkanrenderer_amd import abi, renderer, scenes
+    packed = scenes.proxy_scene(detail=1.0, tex_size=64)
+    sc, osc = renderer.Scene(ctx, packed), oracle.OracleScene(packed)
+    W, H = 1920, 1080
+    cases = [(0, dict(deferred=True)), (40, dict(deferred=True)), (128, dict(debug=2)), (0, dict(debug=5)), (0, dict(debug=6))]
+    try:
+        for pi, kw in cases:
+            u = renderer.make_uniforms(W, H, fly_pose(pi), kw.get("debug", 1))
+            p = abi.make_params(W, H, u, shadow_size=2048, **kw)
+            want = ("rgba8", "tri_id", "depth_bits", "mip_level", "stencil")
+            ref, got = osc.render(p, want=want), sc.render(p, want=want)
+            for k in ("tri_id", "depth_bits", "stencil", "mip_level"):
+                assert np.array_equal(ref[k], got[k]), "pose %d %s %s: %d pixels differ" % (pi, kw, k, int((ref[k] != got[k]).sum()))
+            d = np.abs(ref["rgba8"].astype(np.int32) - got["rgba8"].astype(np.int32))
+            assert d.max() <= 1, "pose %d %s: colour off by %d at %d pixels" % (pi, kw, int(d.max()), int((d > 1).sum()))
+            mse = np.mean(d.astype(np.float64) ** 2)
+            assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 50.0
+    finally:
+        sc.close(); osc.close()
