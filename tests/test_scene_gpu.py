@@ -212,3 +212,36 @@ def test_full_scene_1080p_against_oracle(ctx):
             assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 50.0
     finally:
         sc.close(); osc.close()
+
+
+def test_bin_overflow_is_rerendered(micro):
+    """Hundreds of screen-filling triangles need far more bin entries than the first guess: the frame is rendered
+    again with larger bins and comes out complete."""
+    from vulkanrenderer_amd import abi, renderer
+    n = 120
+    pos, uv, idx = [], [], []
+    for q in range(n):
+        z = -2.0 - 0.01 * q
+        b = len(pos)
+        pos += [(-40.0, -40.0, z), (40.0, -40.0, z), (40.0, 40.0, z), (-40.0, 40.0, z)]
+        uv += [(0, 0), (1, 0), (1, 1), (0, 1)]
+        idx += [b, b + 1, b + 2, b, b + 2, b + 3, b, b + 2, b + 1, b, b + 3, b + 2]   # both windings: one survives the cull
+    pos = np.asarray(pos, np.float32); uv = np.asarray(uv, np.float32)
+    nrm = np.tile(np.asarray([[0, 0, 1]], np.float32), (len(pos), 1))
+    tan = np.tile(np.asarray([[1, 0, 0, 1]], np.float32), (len(pos), 1))
+    from vulkanrenderer_amd.baked_model import pack_tbn
+    mesh = dict(materialId=0, positions=pos, normals=nrm, texcoords=uv, tangents=tan, tangentsComp=pack_tbn(tan, nrm),
+                indices=np.asarray(idx, np.uint32))
+    packed = abi.PackedScene(micro.textures, micro.materials, [mesh])
+    ctx = renderer.Context(0)
+    sc = renderer.Scene(ctx, packed)
+    try:
+        W, H = 1920, 1080
+        u = renderer.make_uniforms(W, H, IDENTITY, 5)
+        od = sc.render(abi.make_params(W, H, u, debug=5), want=("stencil",))["stencil"]
+        assert od.min() == n and od.max() == n, (int(od.min()), int(od.max()))
+        u = renderer.make_uniforms(W, H, IDENTITY, 1)
+        r = sc.render(abi.make_params(W, H, u, deferred=True), want=("tri_id",))["tri_id"]
+        assert set(np.unique(r).tolist()) <= {0, 1, 2, 3}   # the nearest quad (first four triangles) everywhere
+    finally:
+        sc.close(); ctx.close()

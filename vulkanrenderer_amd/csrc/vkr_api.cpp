@@ -99,6 +99,7 @@ struct vkr_context {
 	DevBuf clip, recs, recTiles, recLocal, clipQueue, counters, tileCount, tileCountBig, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
 	uint32_t recCap = 0, binCap = 0;
 	double capScale = 1.0;
+	uint64_t binFloor = 0; // bin entries a pass has been seen to need (from an overflowed attempt)
 	// frame buffers
 	DevBuf vis, depth, triId, gN, gA, colour, colour2, stencil, mip, shadow;
 	// status
@@ -665,7 +666,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if (nTiles == 0 || nTiles > (1u << 24)) return set_error(VKR_E_LIMIT, "tile count %u out of range", nTiles);
 	// one slot per triangle + room for the fan triangles of clipped ones
 	const uint32_t recCap = (uint32_t)std::min<double>(4.0e9, (double)g.count + ((double)g.count * 0.25 + 4096.0) * c->capScale);
-	const uint32_t binCap = (uint32_t)std::min<double>(4.0e9, ((double)recCap * 3.0 + nTiles) * c->capScale);
+	const uint32_t binCap = (uint32_t)std::min<double>(4.0e9, std::max<double>(((double)recCap * 3.0 + nTiles) * c->capScale, (double)c->binFloor));
 	int rc;
 	if ((rc = c->clip.ensure((size_t)s->dev.nVert * sizeof(float4)))) return rc;
 	if ((rc = c->recs.ensure((size_t)recCap * sizeof(SubTri)))) return rc;
@@ -1004,7 +1005,15 @@ extern "C" int vkr_wait(vkr_context* c)
 		std::vector<PendingFrame> redo;
 		for (auto& pf : c->pending)
 			for (uint32_t k = 0; k < pf.nPasses; k++)
-				if (c->hStatus[pf.statusSlot + k].overflow) { redo.push_back(pf); break; }
+				if (c->hStatus[pf.statusSlot + k].overflow) {
+					// the tile scan totals every entry whether or not it fits: size the bins from it
+					for (uint32_t j = 0; j < pf.nPasses; j++) {
+						const uint64_t need = c->hStatus[pf.statusSlot + j].binTotal;
+						c->binFloor = std::max<uint64_t>(c->binFloor, need + need / 8 + 1024);
+					}
+					redo.push_back(pf);
+					break;
+				}
 		c->pending.clear();
 		c->statusUsed = 0;
 		if (redo.empty()) return VKR_OK;
