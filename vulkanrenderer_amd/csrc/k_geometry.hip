@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void k_xform(const float* __restrict__ pos, fl
 template <bool RETURNS>
 __device__ __forceinline__ uint32_t wave_tile_add(uint32_t* counter, uint32_t tile, bool valid)
 {
+	// `counter` may differ between lanes (opaque / alpha-tested counters): `tile` must then identify the pair
 	const int MAXG = 12;
 	const uint32_t lane = threadIdx.x & 63;
 	unsigned long long todo = __ballot(valid);
@@ -48,8 +49,8 @@ __device__ __forceinline__ uint32_t wave_tile_add(uint32_t* counter, uint32_t ti
 	}
 	uint32_t base = 0;
 	if (myCount) {
-		if (RETURNS) base = atomicAdd(&counter[tile], myCount);
-		else atomicAdd(&counter[tile], myCount);
+		if (RETURNS) base = atomicAdd(&counter[tile & 0x7fffffffu], myCount);
+		else atomicAdd(&counter[tile & 0x7fffffffu], myCount);
 	}
 	if (RETURNS) base = __shfl(base, myLeader, 64) + myRank;
 	return base;
@@ -164,12 +165,13 @@ __device__ __forceinline__ bool prepare_subtri(const SetupArgs& a, int32_t X0, i
 // bin), so the fill pass needs no second round of atomics for it.  Records that
 // touch more tiles are counted separately and take their positions, behind the
 // others, from a cursor in the fill pass.
-__device__ __forceinline__ void count_small(const SetupArgs& a, uint32_t slot, uint2 tiles)
+__device__ __forceinline__ void count_small(const SetupArgs& a, uint32_t slot, uint2 tiles, bool alpha)
 {
+	uint32_t* counter = alpha ? a.tileCountA : a.tileCount;
 	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
 	uint32_t k = 0;
 	for (uint32_t ty = ty0; ty <= ty1; ty++)
-		for (uint32_t tx = tx0; tx <= tx1; tx++, k++) a.recLocal[(size_t)slot * 8 + k] = atomicAdd(&a.tileCount[ty * a.view.tilesX + tx], 1u);
+		for (uint32_t tx = tx0; tx <= tx1; tx++, k++) a.recLocal[(size_t)slot * 8 + k] = atomicAdd(&counter[ty * a.view.tilesX + tx], 1u);
 }
 
 __device__ __forceinline__ bool commit_subtri(const SetupArgs& a, uint32_t slot, const SubTri& r, uint2 tiles)
@@ -178,7 +180,7 @@ __device__ __forceinline__ bool commit_subtri(const SetupArgs& a, uint32_t slot,
 	a.recs[slot] = r;
 	a.recTiles[slot] = tiles;
 	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
-	if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 8) { count_small(a, slot, tiles); return true; }
+	if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 8) { count_small(a, slot, tiles, (r.flags & VKR_ST_ALPHA) != 0); return true; }
 	for (uint32_t ty = ty0; ty <= ty1; ty++)
 		for (uint32_t tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tileCountBig[ty * a.view.tilesX + tx], 1u);
 	return true;
@@ -303,10 +305,12 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 	const uint32_t nt = emit ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0u;
 	// one-tile records: grouped by tile inside the wave; the value returned is the record's index in the tile's bin
 	{
-		const uint32_t local = wave_tile_add<true>(a.tileCount, ty0 * a.view.tilesX + tx0, nt == 1);
+		const bool alpha = emit && (rec.flags & VKR_ST_ALPHA);
+		const uint32_t tile = ty0 * a.view.tilesX + tx0;
+		const uint32_t local = wave_tile_add<true>(alpha ? a.tileCountA : a.tileCount, tile | (alpha ? 0x80000000u : 0u), nt == 1);
 		if (nt == 1) a.recLocal[(size_t)slot * 8] = local;
 	}
-	if (nt > 1 && nt <= 8) count_small(a, slot, tiles);
+	if (nt > 1 && nt <= 8) count_small(a, slot, tiles, (rec.flags & VKR_ST_ALPHA) != 0);
 	// records that touch many tiles: the wave counts them together
 	unsigned long long bmask = __ballot(nt > 8);
 	while (bmask) {
@@ -335,7 +339,8 @@ __global__ __launch_bounds__(64) void k_setup_clip(SetupArgs a)
 // ---------------------------------------------------------------------------
 // exclusive scan of the per-tile counts (one workgroup), cursor reset
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ count, const uint32_t* __restrict__ countBig,
+__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ count, const uint32_t* __restrict__ countA,
+                                                      const uint32_t* __restrict__ countBig,
                                                       uint32_t* __restrict__ offset, uint32_t* __restrict__ cursor, uint32_t nTiles,
                                                       uint32_t cap, uint32_t* overflow)
 {
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 	__syncthreads();
 	for (uint32_t base = 0; base < nTiles; base += 1024) {
 		uint32_t i = base + tid;
-		uint32_t v = (i < nTiles) ? count[i] + countBig[i] : 0u;
+		uint32_t v = (i < nTiles) ? count[i] + countA[i] + countBig[i] : 0u;
 		uint32_t s = v; // inclusive scan in the wave
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
@@ -377,12 +382,14 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 	const uint32_t n = min(a.baseCount + *a.recCount, a.recCap);
 	bool has = r < n;
 	uint32_t tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0, key = 0;
+	bool alpha = false;
 	uint2 tr = make_uint2(0xffffffffu, 0u);
 	if (has) tr = a.recTiles[r];
 	has = tr.x != 0xffffffffu; // slot of a triangle that draws nothing
 	if (has) {
 		tx0 = tr.x & 0xffffu; ty0 = tr.x >> 16; tx1 = tr.y & 0xffffu; ty1 = tr.y >> 16;
 		if (a.keys) key = a.recs[r].prim;
+		alpha = (a.recs[r].flags & VKR_ST_ALPHA) != 0;
 	}
 	const uint32_t nt = has ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0;
 	const bool big = nt > 8;
@@ -392,7 +399,8 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 		for (uint32_t ty = ty0; ty <= ty1; ty++)
 			for (uint32_t tx = tx0; tx <= tx1; tx++, k++) {
 				const uint32_t tile = ty * a.tilesX + tx;
-				const uint32_t idx = a.tileOffset[tile] + a.recLocal[(size_t)r * 8 + k];
+				// a tile's bin: records without alpha test, then alpha-tested ones, then those touching many tiles
+				const uint32_t idx = a.tileOffset[tile] + (alpha ? a.tileCount[tile] : 0u) + a.recLocal[(size_t)r * 8 + k];
 				if (idx < a.binCap) {
 					a.binList[idx] = r;
 					if (a.keys) a.keys[idx] = key;
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 		for (uint32_t k = lane; k < cnt; k += 64) {
 			const uint32_t tile = (wy0 + k / w) * a.tilesX + (wx0 + k % w);
 			// behind the entries of the records whose positions the counting pass fixed
-			const uint32_t idx = a.tileOffset[tile] + a.tileCount[tile] + atomicAdd(&a.cursor[tile], 1u);
+			const uint32_t idx = a.tileOffset[tile] + a.tileCount[tile] + a.tileCountA[tile] + atomicAdd(&a.cursor[tile], 1u);
 			if (idx < a.binCap) {
 				a.binList[idx] = wr;
 				if (a.keys) a.keys[idx] = wkey;
@@ -435,10 +443,10 @@ void vkr_launch_setup(hipStream_t s, const SetupArgs& a)
 	hipLaunchKernelGGL(k_setup_clip, dim3(512), dim3(64), 0, s, a);
 }
 
-void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
+void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countA, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
                            uint32_t nTiles, uint32_t cap, uint32_t* overflow)
 {
-	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, count, countBig, offset, cursor, nTiles, cap, overflow);
+	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, count, countA, countBig, offset, cursor, nTiles, cap, overflow);
 }
 
 void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs)

@@ -131,7 +131,11 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 	uint32_t beg = a.tileOffset[tile], end = a.tileOffset[tile + 1];
 	if (end > a.binCap) end = a.binCap;
 	if (beg > end) beg = end;
-	const uint32_t n = end - beg;
+	// the bin: nO records without alpha test, nA alpha-tested ones (left to k_raster_alpha), then the records
+	// that touch many tiles, of either kind
+	const uint32_t nO = min(a.tileCount[tile], end - beg), nA = min(a.tileCountA[tile], end - beg - nO);
+	const uint32_t n = (end - beg) - nA;
+	if (MODE == RASTER_VIS && tid == 0 && nA) sAnyAlpha = 1;
 
 	for (uint32_t base = 0; base < n; base += 256) {
 		// entries are dealt to the four wavefronts round-robin, so a short bin still spreads its
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 		SubTri s;
 		int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
 		if (has) {
-			s = a.recs[a.binList[beg + i]];
+			s = a.recs[a.binList[beg + (i < nO ? i : i + nA)]];
 			if (MODE == RASTER_VIS && (s.flags & VKR_ST_ALPHA)) { sAnyAlpha = 1; has = false; }
 		}
 		if (has) {
@@ -211,10 +215,11 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 // ---------------------------------------------------------------------------
 // Second visibility pass: the alpha-tested sub-triangles (discard on
 // alpha < 0.5, gBufWrite.frag:22-23 / default.frag:91-92) of the tiles that
-// hold any.  One 1024-thread workgroup per such tile, pixel-owner: wavefront w
-// owns the 8x8 block w of the tile and every lane one pixel, whose
+// hold any.  One 256-thread workgroup per 16x16 quadrant of such a tile (four
+// times the workgroups of a per-tile split: the tiles that hold foliage are
+// few and deep), pixel-owner: each wavefront owns one 8x8 block and every lane one pixel, whose
 // (depth | primitive) key it keeps in registers, seeded from the opaque pass.
-// The tile's alpha-tested bin entries are staged through LDS 256 at a time
+// The tile's alpha-tested bin entries are staged through LDS 128 at a time
 // (edge functions, depth plane, interpolation planes, texture description,
 // computed once per entry), and every wavefront walks the staged list:
 //   - entries whose bounding box misses the block, or whose nearest possible
@@ -226,7 +231,8 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 // order of the entries (the key minimum is order-free; a skipped fragment
 // could not have won).
 // ---------------------------------------------------------------------------
-#define ALPHA_CHUNK 256
+#define ALPHA_CHUNK 256 // entries staged per round by k_overshade
+#define ALPHA_STAGE 128 // and by k_raster_alpha (coverage + interpolation data: 27 KB, three workgroups per CU)
 
 struct AlphaCover {          // coverage + depth of one staged entry
 	double e0, e1, e2;       // biased edge values at the tile's first pixel centre
@@ -251,26 +257,73 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 	return v;
 }
 
-__global__ __launch_bounds__(1024) void k_raster_alpha(RasterArgs a)
+// Straight-line footprint of the alpha fetch for a texture whose sizes are powers of two: both levels are always
+// addressed (the second with weight 0 when one level suffices, which leaves the value unchanged), so two
+// fragments' texel loads can be in flight together.  Same arithmetic as vkr_trilinear_alpha_wh.
+struct AlphaFetch {
+	const uint8_t* b0; const uint8_t* b1;
+	LevelTaps t0, t1;
+	float fr;
+};
+
+__device__ __forceinline__ void alpha_fetch_setup(const uint8_t* __restrict__ alphaTexels, const AlphaAttr& t, int px, int py, AlphaFetch& f)
+{
+	TriPlanes pl;
+#pragma unroll
+	for (int k = 0; k < 3; k++) { pl.a[k] = t.a[k]; pl.b[k] = t.b[k]; pl.c[k] = t.c[k]; }
+	pl.Az = pl.Bz = pl.Cz = 0.0;
+	float b[3], uv[2], d[4];
+	vkr_bary_at(pl, px, py, b);
+	vkr_uv_derivs(pl, px, py, b, t.t0, t.t1, t.t2, uv, d);
+	int lv;
+	vkr_lod_split(vkr_rho2_wh((float)t.w0, (float)t.h0, d), t.levels - 1, lv, f.fr);
+	const int lv1 = min(lv + 1, t.levels - 1);
+	const int w0 = max((int)(t.w0 >> lv), 1), h0 = max((int)(t.h0 >> lv), 1);
+	const int w1 = max((int)(t.w0 >> lv1), 1), h1 = max((int)(t.h0 >> lv1), 1);
+	vkr_level_taps<true>(w0, h0, uv[0], uv[1], f.t0);
+	vkr_level_taps<true>(w1, h1, uv[0], uv[1], f.t1);
+	const uint32_t o0 = vkr_level_offset(t.off0, t.w0, t.h0, lv);
+	f.b0 = alphaTexels + o0;
+	f.b1 = alphaTexels + ((lv1 == lv) ? o0 : o0 + (uint32_t)w0 * (uint32_t)h0);
+}
+
+struct AlphaRaw { uint32_t a00, a10, a01, a11, c00, c10, c01, c11; };
+
+__device__ __forceinline__ void alpha_fetch_issue(const AlphaFetch& f, AlphaRaw& r)
+{
+	r.a00 = f.b0[f.t0.i00]; r.a10 = f.b0[f.t0.i10]; r.a01 = f.b0[f.t0.i01]; r.a11 = f.b0[f.t0.i11];
+	r.c00 = f.b1[f.t1.i00]; r.c10 = f.b1[f.t1.i10]; r.c01 = f.b1[f.t1.i01]; r.c11 = f.b1[f.t1.i11];
+}
+
+__device__ __forceinline__ float alpha_fetch_finish(const AlphaFetch& f, const AlphaRaw& r)
+{
+	const float a = vkr_lerp(vkr_lerp(vkr_unorm8(r.a00), vkr_unorm8(r.a10), f.t0.fx), vkr_lerp(vkr_unorm8(r.a01), vkr_unorm8(r.a11), f.t0.fx), f.t0.fy);
+	const float b = vkr_lerp(vkr_lerp(vkr_unorm8(r.c00), vkr_unorm8(r.c10), f.t1.fx), vkr_lerp(vkr_unorm8(r.c01), vkr_unorm8(r.c11), f.t1.fx), f.t1.fy);
+	return (f.fr == 0.0f) ? a : vkr_lerp(a, b, f.fr);
+}
+
+__global__ __launch_bounds__(256) void k_raster_alpha(RasterArgs a)
 {
 	const uint32_t nAlpha = min(a.alphaTileCount[0], a.view.tilesX * a.view.tilesY);
-	if (blockIdx.x >= nAlpha) return;
-	const uint32_t tile = a.alphaTiles[blockIdx.x];
-	__shared__ AlphaCover sCov[ALPHA_CHUNK];
-	__shared__ AlphaAttr sAttr[ALPHA_CHUNK];
+	if (blockIdx.x / 4 >= nAlpha) return;
+	const uint32_t tile = a.alphaTiles[blockIdx.x / 4];
+	const int qx = (int)(blockIdx.x & 1) * 16, qy = (int)((blockIdx.x >> 1) & 1) * 16; // the quadrant, tile-local
+	__shared__ AlphaCover sCov[ALPHA_STAGE];
+	__shared__ AlphaAttr sAttr[ALPHA_STAGE];
 	__shared__ uint32_t sCount;
-	__shared__ uint32_t sZKey[ALPHA_CHUNK];  // depth of the entry's plane at the tile centre
-	__shared__ uint16_t sOrder[ALPHA_CHUNK]; // staged entries, nearest first
+	__shared__ uint32_t sZKey[ALPHA_STAGE];  // depth of the entry's plane at the tile centre
+	__shared__ uint16_t sOrder[ALPHA_STAGE]; // staged entries, nearest first
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
 	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = (int)(a.view.y0 + ty * VKR_TILE);
 	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = min(oy + VKR_TILE, (int)a.view.y1) - 1;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-	const int bxl = (int)(wid & 3) * 8, byl = (int)(wid >> 2) * 8;    // the wave's block, tile-local
-	const int lx = bxl + (int)(lane & 7), ly = byl + (int)(lane >> 3); // the lane's pixel, tile-local
+	const int bxl = qx + (int)(wid & 1) * 8, byl = qy + (int)(wid >> 1) * 8; // the wave's block, tile-local
+	const int lx = bxl + (int)(lane & 7), ly = byl + (int)(lane >> 3);       // the lane's pixel, tile-local
 	const int px = ox + lx, py = oy + ly;
 	const bool inRect = px <= ex && py <= ey;
 	const uint32_t rw = a.view.x1 - a.view.x0;
 	const size_t p = (size_t)(py - (int)a.view.y0) * rw + (size_t)(px - (int)a.view.x0);
+	if (ox + qx > ex || oy + qy > ey) return; // quadrant outside the rectangle (whole workgroup)
 	unsigned long long key = inRect ? a.vis[p] : 0ull;
 	uint32_t wmax = wave_max_u32(inRect ? (uint32_t)(key >> 32) : 0u); // farthest depth held in the block
 	const double dlx = (double)lx, dly = (double)ly;
@@ -279,18 +332,21 @@ __global__ __launch_bounds__(1024) void k_raster_alpha(RasterArgs a)
 	uint32_t beg = a.tileOffset[tile], end = a.tileOffset[tile + 1];
 	if (end > a.binCap) end = a.binCap;
 	if (beg > end) beg = end;
+	// the alpha-tested section of the bin, then the records that touch many tiles (of either kind)
+	const uint32_t nO = min(a.tileCount[tile], end - beg);
+	beg += nO;
 	const uint32_t n = end - beg;
 
-	for (uint32_t base = 0; base < n; base += ALPHA_CHUNK) {
+	for (uint32_t base = 0; base < n; base += ALPHA_STAGE) {
 		if (tid == 0) sCount = 0;
 		__syncthreads();
-		if (tid < ALPHA_CHUNK && base + tid < n) {
+		if (tid < ALPHA_STAGE && base + tid < n) {
 			const uint32_t ri = a.binList[beg + base + tid];
 			const SubTri s = a.recs[ri];
 			if (s.flags & VKR_ST_ALPHA) {
 				int bx0, by0, bx1, by1;
 				tri_bbox(s, bx0, by0, bx1, by1);
-				bx0 = max(bx0, ox); by0 = max(by0, oy); bx1 = min(bx1, ex); by1 = min(by1, ey);
+				bx0 = max(bx0, ox + qx); by0 = max(by0, oy + qy); bx1 = min(bx1, min(ex, ox + qx + 15)); by1 = min(by1, min(ey, oy + qy + 15));
 				if (bx0 <= bx1 && by0 <= by1) {
 					// alpha-tested passes submit in order A, so prim indexes sc.tri directly
 					const uint32_t i0 = a.sc.tri[3 * (size_t)s.prim + 0], i1 = a.sc.tri[3 * (size_t)s.prim + 1],
@@ -335,42 +391,78 @@ __global__ __launch_bounds__(1024) void k_raster_alpha(RasterArgs a)
 			sOrder[rank] = (uint16_t)tid;
 		}
 		__syncthreads();
-		for (uint32_t jj = 0; jj < m; jj++) {
-			const uint32_t j = sOrder[jj];
-			const AlphaCover& c = sCov[j];
-			const uint32_t bb = c.bbox;
-			const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
-			if (x1 < bxl || x0 > bxl + 7 || y1 < byl || y0 > byl + 7) continue; // misses the block (wave-uniform)
-			const double Az = c.Az, Bz = c.Bz, Cz = c.Cz;
-			// nearest depth the plane can take over the block's pixel centres
-			const float znear = (float)fma(Az, bcx, fma(Bz, bcy, Cz)) - ((float)(3.5 * (fabs(Az) + fabs(Bz))) + 2.0e-6f);
-			if (znear > u2f(wmax)) continue;
-			// exact: integers below 2^53
-			const double e0 = fma(c.sy0, dly, fma(c.sx0, dlx, c.e0));
-			const double e1 = fma(c.sy1, dly, fma(c.sx1, dlx, c.e1));
-			const double e2 = fma(c.sy2, dly, fma(c.sx2, dlx, c.e2));
-			bool cand = inRect && lx >= x0 && lx <= x1 && ly >= y0 && ly <= y1 && edges_inside(e0, e1, e2);
-			float z = 0.0f;
-			if (cand) {
-				z = vkr_depth_at(Az, Bz, Cz, px, py);
-				cand = (z >= 0.0f && z <= 1.0f) && !(f2u(z) > (uint32_t)(key >> 32));
-			}
-			if (__ballot(cand) == 0ull) continue;
-			bool upd = false;
-			if (cand) {
-				const AlphaAttr& t = sAttr[j];
-				TriPlanes pl;
-#pragma unroll
-				for (int k = 0; k < 3; k++) { pl.a[k] = t.a[k]; pl.b[k] = t.b[k]; pl.c[k] = t.c[k]; }
-				pl.Az = pl.Bz = pl.Cz = 0.0;
-				float b[3], uv[2], d[4];
-				vkr_bary_at(pl, px, py, b);
-				vkr_uv_derivs(pl, px, py, b, t.t0, t.t1, t.t2, uv, d);
-				const float alpha = vkr_trilinear_alpha_wh(a.sc.alphaTexels, t.off0, t.w0, t.h0, t.levels, uv[0], uv[1], d);
-				if (!(alpha < 0.5f)) {
-					const unsigned long long k2 = ((unsigned long long)f2u(z) << 32) | (unsigned long long)(0xFFFFFFFEu - c.prim);
-					if (k2 < key) { key = k2; upd = true; }
+		// Entries are taken two at a time: the second one's coverage and depth test run against the key as it
+		// is before the first one's alpha test (a fragment tested needlessly cannot change the minimum), so both
+		// fragments' texel loads are in flight together - the pass is bound by that round trip.
+		uint32_t jj = 0;
+		while (jj < m) {
+			uint32_t cj[2] = { 0, 0 };
+			bool cc[2] = { false, false };
+			float cz[2] = { 0.0f, 0.0f };
+			int nc = 0;
+			while (jj < m && nc < 2) {
+				const uint32_t j = sOrder[jj++];
+				const AlphaCover& c = sCov[j];
+				const uint32_t bb = c.bbox;
+				const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
+				if (x1 < bxl || x0 > bxl + 7 || y1 < byl || y0 > byl + 7) continue; // misses the block (wave-uniform)
+				const double Az = c.Az, Bz = c.Bz, Cz = c.Cz;
+				// nearest depth the plane can take over the block's pixel centres
+				const float znear = (float)fma(Az, bcx, fma(Bz, bcy, Cz)) - ((float)(3.5 * (fabs(Az) + fabs(Bz))) + 2.0e-6f);
+				if (znear > u2f(wmax)) continue;
+				// exact: integers below 2^53
+				const double e0 = fma(c.sy0, dly, fma(c.sx0, dlx, c.e0));
+				const double e1 = fma(c.sy1, dly, fma(c.sx1, dlx, c.e1));
+				const double e2 = fma(c.sy2, dly, fma(c.sx2, dlx, c.e2));
+				bool cand = inRect && lx >= x0 && lx <= x1 && ly >= y0 && ly <= y1 && edges_inside(e0, e1, e2);
+				float z = 0.0f;
+				if (cand) {
+					z = vkr_depth_at(Az, Bz, Cz, px, py);
+					cand = (z >= 0.0f && z <= 1.0f) && !(f2u(z) > (uint32_t)(key >> 32));
 				}
+				if (__ballot(cand) == 0ull) continue;
+				if (nc == 0) { cj[0] = j; cc[0] = cand; cz[0] = z; } else { cj[1] = j; cc[1] = cand; cz[1] = z; }
+				nc++;
+			}
+			if (nc == 0) break;
+			const AlphaAttr& tA = sAttr[cj[0]];
+			const AlphaAttr& tB = sAttr[cj[1]];
+			const bool pow2 = ((tA.w0 & (tA.w0 - 1)) | (tA.h0 & (tA.h0 - 1)) | (tB.w0 & (tB.w0 - 1)) | (tB.h0 & (tB.h0 - 1))) == 0;
+			float alphaA, alphaB = 0.0f;
+			if (nc == 2 && pow2) {
+				AlphaFetch fA, fB;
+				AlphaRaw rA, rB;
+				alpha_fetch_setup(a.sc.alphaTexels, tA, px, py, fA);
+				alpha_fetch_setup(a.sc.alphaTexels, tB, px, py, fB);
+				alpha_fetch_issue(fA, rA);
+				alpha_fetch_issue(fB, rB);
+				alphaA = alpha_fetch_finish(fA, rA);
+				alphaB = alpha_fetch_finish(fB, rB);
+			} else {
+				TriPlanes pl;
+				float b[3], uv[2], d[4];
+#pragma unroll
+				for (int k = 0; k < 3; k++) { pl.a[k] = tA.a[k]; pl.b[k] = tA.b[k]; pl.c[k] = tA.c[k]; }
+				pl.Az = pl.Bz = pl.Cz = 0.0;
+				vkr_bary_at(pl, px, py, b);
+				vkr_uv_derivs(pl, px, py, b, tA.t0, tA.t1, tA.t2, uv, d);
+				alphaA = vkr_trilinear_alpha_wh(a.sc.alphaTexels, tA.off0, tA.w0, tA.h0, tA.levels, uv[0], uv[1], d);
+				if (nc == 2) {
+#pragma unroll
+					for (int k = 0; k < 3; k++) { pl.a[k] = tB.a[k]; pl.b[k] = tB.b[k]; pl.c[k] = tB.c[k]; }
+					vkr_bary_at(pl, px, py, b);
+					vkr_uv_derivs(pl, px, py, b, tB.t0, tB.t1, tB.t2, uv, d);
+					alphaB = vkr_trilinear_alpha_wh(a.sc.alphaTexels, tB.off0, tB.w0, tB.h0, tB.levels, uv[0], uv[1], d);
+				}
+			}
+			bool upd = false;
+			if (cc[0] && !(alphaA < 0.5f)) {
+				const unsigned long long k2 = ((unsigned long long)f2u(cz[0]) << 32) | (unsigned long long)(0xFFFFFFFEu - sCov[cj[0]].prim);
+				if (k2 < key) { key = k2; upd = true; }
+			}
+			if (nc == 2 && cc[1] && !(alphaB < 0.5f)) {
+				const unsigned long long k2 = ((unsigned long long)f2u(cz[1]) << 32) | (unsigned long long)(0xFFFFFFFEu - sCov[cj[1]].prim);
+				if (k2 < key) { key = k2; upd = true; }
 			}
 			if (__ballot(upd)) wmax = wave_max_u32(inRect ? (uint32_t)(key >> 32) : 0u);
 		}
@@ -461,7 +553,7 @@ void vkr_launch_raster(hipStream_t s, int mode, const RasterArgs& a)
 	if (!nTiles) return;
 	if (mode == RASTER_VIS) {
 		hipLaunchKernelGGL(k_raster<RASTER_VIS>, dim3(nTiles), dim3(256), 0, s, a);
-		if (a.alphaPass) hipLaunchKernelGGL(k_raster_alpha, dim3(nTiles), dim3(1024), 0, s, a);
+		if (a.alphaPass) hipLaunchKernelGGL(k_raster_alpha, dim3(nTiles * 4), dim3(256), 0, s, a);
 	}
 	else if (mode == RASTER_SHADOW) hipLaunchKernelGGL(k_raster<RASTER_SHADOW>, dim3(nTiles), dim3(256), 0, s, a);
 	else hipLaunchKernelGGL(k_raster<RASTER_COUNT>, dim3(nTiles), dim3(256), 0, s, a);

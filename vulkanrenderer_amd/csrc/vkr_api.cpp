@@ -96,7 +96,7 @@ struct vkr_context {
 	float* dThresh = nullptr; // 255
 	float hDecode[256], hThresh[255];
 	// geometry scratch
-	DevBuf clip, recs, recTiles, recLocal, clipQueue, counters, tileCount, tileCountBig, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
+	DevBuf clip, recs, recTiles, recLocal, clipQueue, counters, tileCount, tileCountA, tileCountBig, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
 	uint32_t recCap = 0, binCap = 0;
 	double capScale = 1.0;
 	uint64_t binFloor = 0; // bin entries a pass has been seen to need (from an overflowed attempt)
@@ -318,7 +318,7 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf* bufs[] = { &c->clip, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->counters, &c->tileCount, &c->tileCountBig, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
+	DevBuf* bufs[] = { &c->clip, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->counters, &c->tileCount, &c->tileCountA, &c->tileCountBig, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
 		&c->binKeys, &c->binList2, &c->binKeys2, &c->sortTemp, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
 		&c->colour2, &c->stencil, &c->mip, &c->shadow };
 	for (DevBuf* b : bufs) b->release();
@@ -676,6 +676,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if ((rc = c->counters.ensure(64))) return rc;
 	if ((rc = c->tileCount.ensure((size_t)nTiles * 4))) return rc;
 	if ((rc = c->tileCountBig.ensure((size_t)nTiles * 4))) return rc;
+	if ((rc = c->tileCountA.ensure((size_t)nTiles * 4))) return rc;
 	if ((rc = c->tileOffset.ensure((size_t)(nTiles + 1) * 4))) return rc;
 	if ((rc = c->cursor.ensure((size_t)nTiles * 4))) return rc;
 	if ((rc = c->tileFlags.ensure((size_t)nTiles * 4))) return rc;
@@ -686,6 +687,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	HIP_CHECK(hipMemsetAsync(counters, 0, 64, c->stream));
 	HIP_CHECK(hipMemsetAsync(c->tileCount.p, 0, (size_t)nTiles * 4, c->stream));
 	HIP_CHECK(hipMemsetAsync(c->tileCountBig.p, 0, (size_t)nTiles * 4, c->stream));
+	HIP_CHECK(hipMemsetAsync(c->tileCountA.p, 0, (size_t)nTiles * 4, c->stream));
 	{
 		StageTimer t(c, ST_XFORM);
 		vkr_launch_xform(c->stream, s->dev.pos, c->clip.as<float4>(), s->dev.nVert, g.M);
@@ -699,20 +701,20 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 		a.guard = vkr_guard_band(g.view.W, g.view.H);
 		a.recs = c->recs.as<SubTri>(); a.recTiles = c->recTiles.as<uint2>(); a.recCap = recCap;
 		a.recCount = counters; a.tileCount = c->tileCount.as<uint32_t>(); a.overflow = counters + 1;
-		a.tileCountBig = c->tileCountBig.as<uint32_t>(); a.recLocal = c->recLocal.as<uint32_t>();
+		a.tileCountBig = c->tileCountBig.as<uint32_t>(); a.tileCountA = c->tileCountA.as<uint32_t>(); a.recLocal = c->recLocal.as<uint32_t>();
 		a.clipQueue = c->clipQueue.as<uint32_t>(); a.clipCount = counters + 3;
 		vkr_launch_setup(c->stream, a);
 	}
 	{
 		StageTimer t(c, ST_BIN_SCAN);
-		vkr_launch_scan_tiles(c->stream, c->tileCount.as<uint32_t>(), c->tileCountBig.as<uint32_t>(), c->tileOffset.as<uint32_t>(), c->cursor.as<uint32_t>(), nTiles,
+		vkr_launch_scan_tiles(c->stream, c->tileCount.as<uint32_t>(), c->tileCountA.as<uint32_t>(), c->tileCountBig.as<uint32_t>(), c->tileOffset.as<uint32_t>(), c->cursor.as<uint32_t>(), nTiles,
 		                      binCap, counters + 1);
 	}
 	{
 		StageTimer t(c, ST_BIN_FILL);
 		BinFillArgs b;
 		b.recs = c->recs.as<SubTri>(); b.recTiles = c->recTiles.as<uint2>(); b.recCount = counters; b.baseCount = g.count; b.recCap = recCap;
-		b.tileOffset = c->tileOffset.as<uint32_t>(); b.tileCount = c->tileCount.as<uint32_t>(); b.recLocal = c->recLocal.as<uint32_t>(); b.cursor = c->cursor.as<uint32_t>(); b.binList = c->binList.as<uint32_t>();
+		b.tileOffset = c->tileOffset.as<uint32_t>(); b.tileCount = c->tileCount.as<uint32_t>(); b.tileCountA = c->tileCountA.as<uint32_t>(); b.recLocal = c->recLocal.as<uint32_t>(); b.cursor = c->cursor.as<uint32_t>(); b.binList = c->binList.as<uint32_t>();
 		b.keys = g.keys ? c->binKeys.as<uint32_t>() : nullptr; b.binCap = binCap; b.tilesX = g.view.tilesX;
 		vkr_launch_bin_fill(c->stream, b, recCap);
 	}
@@ -727,7 +729,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 static void fill_raster_args(vkr_context* c, const vkr_scene* s, const ViewDev& view, RasterArgs& r)
 {
 	r.sc = s->dev; r.view = view; r.clip = c->clip.as<float4>(); r.recs = c->recs.as<SubTri>();
-	r.tileOffset = c->tileOffset.as<uint32_t>(); r.binList = c->binList.as<uint32_t>(); r.binCap = c->binCap;
+	r.tileOffset = c->tileOffset.as<uint32_t>(); r.tileCount = c->tileCount.as<uint32_t>(); r.tileCountA = c->tileCountA.as<uint32_t>(); r.binList = c->binList.as<uint32_t>(); r.binCap = c->binCap;
 	r.vis = nullptr; r.depthOut = nullptr; r.countOut = nullptr;
 	r.alphaTiles = c->tileFlags.as<uint32_t>(); r.alphaTileCount = c->counters.as<uint32_t>() + 2; r.alphaPass = 0;
 }

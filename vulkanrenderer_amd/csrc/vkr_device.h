@@ -359,6 +359,7 @@ struct LevelTaps {
 	float fx, fy;
 };
 
+template <bool POW2 = false>
 __device__ __forceinline__ void vkr_level_taps(int w, int h, float u, float v, LevelTaps& o)
 {
 	float x = u * (float)w - 0.5f;
@@ -367,7 +368,8 @@ __device__ __forceinline__ void vkr_level_taps(int w, int h, float u, float v, L
 	if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
 	float x0f = floorf(x), y0f = floorf(y);
 	o.fx = x - x0f; o.fy = y - y0f;
-	int x0 = vkr_wrap((int)x0f, w), y0 = vkr_wrap((int)y0f, h);
+	// POW2: the caller knows both sizes are powers of two (no branch, no division)
+	int x0 = POW2 ? ((int)x0f & (w - 1)) : vkr_wrap((int)x0f, w), y0 = POW2 ? ((int)y0f & (h - 1)) : vkr_wrap((int)y0f, h);
 	int x1 = x0 + 1, y1 = y0 + 1;
 	if (x1 == w) x1 = 0;
 	if (y1 == h) y1 = 0;

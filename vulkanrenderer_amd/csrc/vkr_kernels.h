@@ -16,7 +16,8 @@ struct SetupArgs {
 	uint2* recTiles;
 	uint32_t recCap;
 	uint32_t* recCount;   // records of clipped triangles, stored from slot `count` on
-	uint32_t* tileCount;    // entries of records touching <= 8 tiles
+	uint32_t* tileCount;    // entries of records touching <= 8 tiles, no alpha test
+	uint32_t* tileCountA;   // the same, alpha-tested records
 	uint32_t* tileCountBig; // entries of records touching more
 	uint32_t* recLocal;     // 8 per record slot: index inside each touched tile's bin (records touching <= 8 tiles)
 	uint32_t* overflow;
@@ -31,7 +32,8 @@ struct BinFillArgs {
 	uint32_t baseCount;       // triangles of the pass = one-per-triangle slots
 	uint32_t recCap;
 	const uint32_t* tileOffset;
-	const uint32_t* tileCount; // entries per tile fixed by the counting pass
+	const uint32_t* tileCount; // entries per tile fixed by the counting pass (no alpha test / alpha-tested)
+	const uint32_t* tileCountA;
 	const uint32_t* recLocal;
 	uint32_t* cursor;
 	uint32_t* binList;
@@ -48,6 +50,8 @@ struct RasterArgs {
 	const float4* clip;
 	const SubTri* recs;
 	const uint32_t* tileOffset;
+	const uint32_t* tileCount;  // a tile's bin holds tileCount entries without alpha test, then tileCountA alpha-tested
+	const uint32_t* tileCountA; // ones, then the records that touch more than 8 tiles (either kind)
 	const uint32_t* binList;
 	uint32_t binCap;
 	unsigned long long* vis; // RASTER_VIS: rect-sized visibility buffer
@@ -97,7 +101,7 @@ struct LightArgs {
 
 void vkr_launch_xform(hipStream_t s, const float* pos, float4* clip, uint32_t nVert, const Mat4& M);
 void vkr_launch_setup(hipStream_t s, const SetupArgs& a);
-void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
+void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countA, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
                            uint32_t nTiles, uint32_t cap, uint32_t* overflow);
 void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs);
 void vkr_launch_raster(hipStream_t s, int mode, const RasterArgs& a);
