@@ -302,7 +302,9 @@ __device__ __forceinline__ float alpha_fetch_finish(const AlphaFetch& f, const A
 	return (f.fr == 0.0f) ? a : vkr_lerp(a, b, f.fr);
 }
 
-__global__ __launch_bounds__(256) void k_raster_alpha(RasterArgs a)
+#define ALPHA_PARTS 1 // wavefronts that share one 8x8 block, each taking every fourth staged entry
+
+__global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a)
 {
 	const uint32_t nAlpha = min(a.alphaTileCount[0], a.view.tilesX * a.view.tilesY);
 	if (blockIdx.x / 4 >= nAlpha) return;
@@ -313,11 +315,20 @@ __global__ __launch_bounds__(256) void k_raster_alpha(RasterArgs a)
 	__shared__ uint32_t sCount;
 	__shared__ uint32_t sZKey[ALPHA_STAGE];  // depth of the entry's plane at the tile centre
 	__shared__ uint16_t sOrder[ALPHA_STAGE]; // staged entries, nearest first
+	__shared__ uint16_t sListJ[4][ALPHA_STAGE];   // per block of the quadrant: the staged entries whose bounding box touches it,
+	__shared__ float sListZ[4][ALPHA_STAGE];      // nearest first, with the nearest depth their plane can take over the block
+	__shared__ uint32_t sListN[4], sCnt0[4];
+	__shared__ unsigned long long sKey[ALPHA_PARTS][4][64]; // per-chunk exchange of the keys of the wavefronts that share a block
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
 	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = (int)(a.view.y0 + ty * VKR_TILE);
 	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = min(oy + VKR_TILE, (int)a.view.y1) - 1;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-	const int bxl = qx + (int)(wid & 1) * 8, byl = qy + (int)(wid >> 1) * 8; // the wave's block, tile-local
+	// wavefront -> (block of the quadrant, part): the ALPHA_PARTS wavefronts of a block each walk every
+	// ALPHA_PARTS-th staged entry on their own copy of the block's keys and take the minimum after each chunk;
+	// the evaluation of one fragment is a long dependent chain, so the deep tiles are bound by how many
+	// wavefronts work on them
+	const uint32_t blk = wid & 3u, part = wid >> 2;
+	const int bxl = qx + (int)(blk & 1) * 8, byl = qy + (int)(blk >> 1) * 8; // the wave's block, tile-local
 	const int lx = bxl + (int)(lane & 7), ly = byl + (int)(lane >> 3);       // the lane's pixel, tile-local
 	const int px = ox + lx, py = oy + ly;
 	const bool inRect = px <= ex && py <= ey;
@@ -391,25 +402,60 @@ __global__ __launch_bounds__(256) void k_raster_alpha(RasterArgs a)
 			sOrder[rank] = (uint16_t)tid;
 		}
 		__syncthreads();
+		// Per block, the list of the entries that can touch it, in near-to-far order (ranks 0..63 are handled by
+		// wavefront 0, 64..127 by wavefront 1; positions by ballot + popcount), so that the walk below reads a
+		// compact list instead of testing every staged entry.
+		{
+			const bool valid = tid < m;
+			uint32_t j = 0, bb = 0x0000ffffu;
+			double Az = 0.0, Bz = 0.0, Cz = 0.0;
+			if (valid) { j = sOrder[tid]; bb = sCov[j].bbox; Az = sCov[j].Az; Bz = sCov[j].Bz; Cz = sCov[j].Cz; }
+			const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
+			const float slack = (float)(3.5 * (fabs(Az) + fabs(Bz))) + 2.0e-6f;
+			uint32_t pos[4];
+			bool ov[4];
+			float zn[4];
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				const int bx = qx + (b & 1) * 8, by = qy + (b >> 1) * 8;
+				ov[b] = valid && !(x1 < bx || x0 > bx + 7 || y1 < by || y0 > by + 7);
+				// nearest depth the plane can take over the block's pixel centres
+				zn[b] = (float)fma(Az, (double)(ox + bx) + 4.0, fma(Bz, (double)(oy + by) + 4.0, Cz)) - slack;
+				const unsigned long long mask = __ballot(ov[b]);
+				pos[b] = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+				if (tid < 128 && lane == 0) { if (wid == 0) sCnt0[b] = (uint32_t)__popcll(mask); else sListN[b] = (uint32_t)__popcll(mask); }
+			}
+			__syncthreads();
+			if (tid < 128) {
+#pragma unroll
+				for (int b = 0; b < 4; b++)
+					if (ov[b]) {
+						const uint32_t at = pos[b] + (wid == 1 ? sCnt0[b] : 0u);
+						sListJ[b][at] = (uint16_t)j;
+						sListZ[b][at] = zn[b];
+					}
+			}
+			__syncthreads();
+		}
 		// Entries are taken two at a time: the second one's coverage and depth test run against the key as it
 		// is before the first one's alpha test (a fragment tested needlessly cannot change the minimum), so both
-		// fragments' texel loads are in flight together - the pass is bound by that round trip.
-		uint32_t jj = 0;
-		while (jj < m) {
+		// fragments' texel loads are in flight together.
+		const uint32_t nb = sCnt0[blk] + sListN[blk];
+		uint32_t jj = part;
+		while (jj < nb) {
 			uint32_t cj[2] = { 0, 0 };
 			bool cc[2] = { false, false };
 			float cz[2] = { 0.0f, 0.0f };
 			int nc = 0;
-			while (jj < m && nc < 2) {
-				const uint32_t j = sOrder[jj++];
+			while (jj < nb && nc < 2) {
+				const uint32_t j = sListJ[blk][jj];
+				const float znear = sListZ[blk][jj];
+				jj += ALPHA_PARTS;
+				if (znear > u2f(wmax)) continue;
 				const AlphaCover& c = sCov[j];
 				const uint32_t bb = c.bbox;
 				const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
-				if (x1 < bxl || x0 > bxl + 7 || y1 < byl || y0 > byl + 7) continue; // misses the block (wave-uniform)
 				const double Az = c.Az, Bz = c.Bz, Cz = c.Cz;
-				// nearest depth the plane can take over the block's pixel centres
-				const float znear = (float)fma(Az, bcx, fma(Bz, bcy, Cz)) - ((float)(3.5 * (fabs(Az) + fabs(Bz))) + 2.0e-6f);
-				if (znear > u2f(wmax)) continue;
 				// exact: integers below 2^53
 				const double e0 = fma(c.sy0, dly, fma(c.sx0, dlx, c.e0));
 				const double e1 = fma(c.sy1, dly, fma(c.sx1, dlx, c.e1));
@@ -466,9 +512,18 @@ __global__ __launch_bounds__(256) void k_raster_alpha(RasterArgs a)
 			}
 			if (__ballot(upd)) wmax = wave_max_u32(inRect ? (uint32_t)(key >> 32) : 0u);
 		}
-		__syncthreads(); // the stage is rewritten by the next chunk
+		// the block's wavefronts agree on the nearest key found so far
+		sKey[part][blk][lane] = key;
+		__syncthreads(); // also: the stage is rewritten by the next chunk
+		{
+			unsigned long long k = key;
+#pragma unroll
+			for (int q = 0; q < ALPHA_PARTS; q++) { const unsigned long long o = sKey[q][blk][lane]; k = (o < k) ? o : k; }
+			if (__ballot(k != key)) { key = k; wmax = wave_max_u32(inRect ? (uint32_t)(key >> 32) : 0u); }
+		}
+		__syncthreads();
 	}
-	if (inRect) a.vis[p] = key;
+	if (inRect && part == 0) a.vis[p] = key;
 }
 
 // ---------------------------------------------------------------------------
@@ -553,7 +608,7 @@ void vkr_launch_raster(hipStream_t s, int mode, const RasterArgs& a)
 	if (!nTiles) return;
 	if (mode == RASTER_VIS) {
 		hipLaunchKernelGGL(k_raster<RASTER_VIS>, dim3(nTiles), dim3(256), 0, s, a);
-		if (a.alphaPass) hipLaunchKernelGGL(k_raster_alpha, dim3(nTiles * 4), dim3(256), 0, s, a);
+		if (a.alphaPass) hipLaunchKernelGGL(k_raster_alpha, dim3(nTiles * 4), dim3(256 * ALPHA_PARTS), 0, s, a);
 	}
 	else if (mode == RASTER_SHADOW) hipLaunchKernelGGL(k_raster<RASTER_SHADOW>, dim3(nTiles), dim3(256), 0, s, a);
 	else hipLaunchKernelGGL(k_raster<RASTER_COUNT>, dim3(nTiles), dim3(256), 0, s, a);
