@@ -140,7 +140,7 @@ __device__ __forceinline__ bool commit_subtri(const SetupArgs& a, uint32_t slot,
 {
 	if (slot >= a.recCap) { atomicOr(a.overflow, 1u); return false; }
 	a.recs[slot] = r;
-	a.recTiles[slot] = tiles;
+	a.recTiles[slot] = make_uint2(tiles.x, tiles.y | ((r.flags & VKR_ST_ALPHA) ? 0x80000000u : 0u));
 	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
 	if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 8) { count_small(a, slot, tiles, (r.flags & VKR_ST_ALPHA) != 0); return true; }
 	for (uint32_t ty = ty0; ty <= ty1; ty++)
@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 	// nothing carry an empty tile range.
 	const uint32_t slot = t - a.first;
 	if (t < a.first + a.count) {
-		if (emit) { a.recs[slot] = rec; a.recTiles[slot] = tiles; }
+		// bit 31 of the second word: alpha-tested (bin fill then needs nothing else from the record)
+		if (emit) { a.recs[slot] = rec; a.recTiles[slot] = make_uint2(tiles.x, tiles.y | ((rec.flags & VKR_ST_ALPHA) ? 0x80000000u : 0u)); }
 		else a.recTiles[slot] = make_uint2(0xffffffffu, 0u);
 	}
 	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
@@ -384,9 +385,9 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 	if (has) tr = a.recTiles[r];
 	has = tr.x != 0xffffffffu; // slot of a triangle that draws nothing
 	if (has) {
-		tx0 = tr.x & 0xffffu; ty0 = tr.x >> 16; tx1 = tr.y & 0xffffu; ty1 = tr.y >> 16;
+		tx0 = tr.x & 0xffffu; ty0 = tr.x >> 16; tx1 = tr.y & 0xffffu; ty1 = (tr.y >> 16) & 0x7fffu;
 		if (a.keys) key = a.recs[r].prim;
-		alpha = (a.recs[r].flags & VKR_ST_ALPHA) != 0;
+		alpha = (tr.y & 0x80000000u) != 0;
 	}
 	const uint32_t nt = has ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0;
 	const bool big = nt > 8;
