@@ -1,5 +1,5 @@
 // k_light.hip — full-screen passes: deferred brazier lighting, the overdraw /
-// overshading colour ramp, the mosaic post-process, and mip-chain generation.
+// overshading colour ramp and the mosaic post-process.
 // These produce colour only (parity within 1/255), so this file is compiled
 // with floating-point contraction enabled and uses the hardware's fast
 // reciprocal / rsqrt / exp2.

@@ -1,14 +1,17 @@
-// k_raster.hip — tile rasteriser.
+// k_raster.hip — tile rasterisers.
 //
-// One workgroup owns one 32x32 screen tile whose visibility buffer lives in
-// LDS.  The tile's bin (indices of the sub-triangles that touch it) is walked
-// 256 entries at a time: small sub-triangles are scan-converted one per lane,
-// large or alpha-tested ones by a whole wavefront (one lane per pixel of an
-// 8x8 block).  Depth test + write is a single 64-bit LDS atomicMin on
+// k_raster<MODE>: one workgroup owns one 32x32 screen tile whose visibility
+// buffer lives in LDS.  The tile's bin (indices of the sub-triangles that
+// touch it) is walked 256 entries at a time, dealt round-robin to the four
+// wavefronts: small sub-triangles are scan-converted one per lane, large ones
+// by a whole wavefront (one lane per pixel of an 8x8 block).  Depth test +
+// write is a single 64-bit LDS atomicMin on
 // (depthBits << 32) | (0xFFFFFFFE - prim): smaller depth wins and, at equal
 // depth, the later primitive wins, which is VK_COMPARE_OP_LESS_OR_EQUAL
 // applied in submission order (main/main.cpp:2321-2327).  The finished tile
 // is written to HBM once, coalesced.
+// k_raster_alpha: the alpha-tested sub-triangles, pixel-owner (see below).
+// k_overshade: the order-dependent overshading counter, pixel-owner.
 //
 // Replaces the fixed-function rasteriser + depth/stencil unit for the draws of
 // main/main.cpp:3873-3934 (G-buffer pass), :3968-3982 (shadow pass),
@@ -59,16 +62,6 @@ __device__ __forceinline__ void tri_bbox(const SubTri& s, int& px0, int& py0, in
 	int32_t ymin = min(s.Y0, min(s.Y1, s.Y2)), ymax = max(s.Y0, max(s.Y1, s.Y2));
 	px0 = (xmin - 128 + 255) >> 8; px1 = (xmax - 128) >> 8;
 	py0 = (ymin - 128 + 255) >> 8; py1 = (ymax - 128) >> 8;
-}
-
-// Alpha test of gBufWrite.frag:22-23 / default.frag:91-92 for one fragment.
-__device__ __forceinline__ bool alpha_pass(const RasterArgs& a, const TriPlanes& pl, float2 t0, float2 t1, float2 t2,
-                                           const TexInfo& tex, int px, int py)
-{
-	float b[3], uv[2], d[4];
-	vkr_bary_at(pl, px, py, b);
-	vkr_uv_derivs(pl, px, py, b, t0, t1, t2, uv, d);
-	return !(vkr_trilinear_alpha(a.sc, tex, uv[0], uv[1], d) < 0.5f);
 }
 
 template <int MODE>
@@ -338,7 +331,6 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 	unsigned long long key = inRect ? a.vis[p] : 0ull;
 	uint32_t wmax = wave_max_u32(inRect ? (uint32_t)(key >> 32) : 0u); // farthest depth held in the block
 	const double dlx = (double)lx, dly = (double)ly;
-	const double bcx = (double)(ox + bxl) + 4.0, bcy = (double)(oy + byl) + 4.0; // block centre (between pixel centres)
 
 	uint32_t beg = a.tileOffset[tile], end = a.tileOffset[tile + 1];
 	if (end > a.binCap) end = a.binCap;

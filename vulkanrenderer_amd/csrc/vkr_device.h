@@ -14,7 +14,6 @@
 #define VKR_MAX_SUBTRI 6       // a triangle clipped by near + 4 guard planes: <= 8 vertices
 #define VKR_NUM_LIGHTS_K 21     // deferredShading.frag:5
 #define VKR_NO_PRIM 0xffffffffu
-#define VKR_ALPHA_SLICES 1      // workgroups a tile's alpha-tested bin entries are spread over
 
 // Guard band in NDC half-widths: small enough that the snapped coordinates
 // keep every edge function below 2^53, so edges are exact in double.
@@ -494,16 +493,6 @@ __device__ __forceinline__ void vkr_trilinear(const SceneDev& sc, const TexInfo&
 	TexTaps tp;
 	vkr_make_taps(t, u, v, d, tp);
 	vkr_fetch<15>(sc, t, tp, sc.srgbDecode, out);
-}
-
-// alpha channel only (the alpha test needs nothing else)
-__device__ __forceinline__ float vkr_trilinear_alpha(const SceneDev& sc, const TexInfo& t, float u, float v, const float d[4])
-{
-	TexTaps tp;
-	float out[4];
-	vkr_make_taps(t, u, v, d, tp);
-	vkr_fetch<8>(sc, t, tp, nullptr, out);
-	return out[3];
 }
 
 // TBN decode (default.vert:57-81): GLSL mat3 column-major m[c*3+r]
