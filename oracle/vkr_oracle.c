@@ -806,6 +806,7 @@ typedef struct {
 	const ora_scene* sc;
 	const vkr_frame_params* fp;
 	uint32_t W, H;
+	uint32_t sy0, sy1;  /* scissor rows [sy0, sy1) of the colour passes (ora_render_rows); the shadow pass ignores it */
 	int pipe;
 	/* attachments */
 	float* depth;       /* W*H */
@@ -1083,6 +1084,10 @@ static void raster_prim(Frame* f, int cull, uint32_t W, uint32_t H)
 		if (px0 < 0) px0 = 0; if (py0 < 0) py0 = 0;
 		if (px1 > (int64_t)W - 1) px1 = (int64_t)W - 1;
 		if (py1 > (int64_t)H - 1) py1 = (int64_t)H - 1;
+		if (f->pipe != PIPE_SHADOW) {
+			if (py0 < (int64_t)f->sy0) py0 = (int64_t)f->sy0;
+			if (py1 > (int64_t)f->sy1 - 1) py1 = (int64_t)f->sy1 - 1;
+		}
 		if (px0 > px1 || py0 > py1) continue;
 		/* edge i: from vertex i to vertex (i+1)%3; E = dx*(py-y) - dy*(px-x) */
 		int64_t dx[3], dy[3]; int tl[3];
@@ -1202,7 +1207,7 @@ static void deferred_light_pass(Frame* f)
 	mat4_inverse(u->sceneUniforms.camera, invCam);
 	mat4_inverse(u->sceneUniforms.projection, invProj);
 	mat4_mul(invCam, invProj, invPC);
-	for (uint32_t py = 0; py < f->H; py++)
+	for (uint32_t py = f->sy0; py < f->sy1; py++)
 		for (uint32_t px = 0; px < f->W; px++) {
 			size_t p = (size_t)py * f->W + px;
 			float depth = f->depth[p];
@@ -1300,13 +1305,21 @@ static void forward_passes(Frame* f)
 	draw_range(f, sc->orderA, 0, sc->nPrim, u->sceneUniforms.projCam, 1, 0, f->W, f->H);
 }
 
-/* One frame.  Full frame only (rect fields ignored); all outputs host memory. */
-ORA_API int ora_render(const ora_scene* sc, const vkr_frame_params* fp, const vkr_frame_out* out)
+/* Rows [y0, y1) of one frame (rect fields of the parameters ignored); all outputs host memory, full-frame
+ * sized, only those rows written (the shadow map whole).  Calls for disjoint row ranges of the same frame
+ * may run concurrently on the same output buffers: the scene is read-only and every call owns its
+ * attachments, which is how the CPU baseline uses several cores. */
+ORA_API int ora_render_rows(const ora_scene* sc, const vkr_frame_params* fp, const vkr_frame_out* out, uint32_t y0, uint32_t y1)
 {
 	init_tables();
 	Frame f;
 	memset(&f, 0, sizeof f);
 	f.sc = sc; f.fp = fp; f.W = fp->width; f.H = fp->height;
+	if (y1 > f.H) y1 = f.H;
+	if (y0 >= y1) return 1;
+	f.sy0 = y0; f.sy1 = y1;
+	/* the mosaic pass reads the top row of each 3-row block of the image below it */
+	if (fp->mosaicEffect) { const uint32_t top = y0 - (y0 % 3u); f.sy0 = top > 4u ? top - 4u : 0u; }
 	f.S = fp->shadow_size ? fp->shadow_size : 2048;
 	size_t n = (size_t)f.W * f.H;
 	if (n == 0) return 1;
@@ -1357,16 +1370,25 @@ ORA_API int ora_render(const ora_scene* sc, const vkr_frame_params* fp, const vk
 		f.rgba = dst;
 	}
 
-	if (out->rgba8) memcpy(out->rgba8, f.rgba, n * 4);
-	if (out->tri_id) memcpy(out->tri_id, f.tri, n * 4);
-	if (out->depth_bits) memcpy(out->depth_bits, f.depth, n * 4);
-	if (out->mip_level) memcpy(out->mip_level, f.mip, n);
-	if (out->stencil) memcpy(out->stencil, f.stencil, n);
-	if (out->gbuf_normal) memcpy(out->gbuf_normal, f.gN, n * 8);
-	if (out->gbuf_albedo) memcpy(out->gbuf_albedo, f.gA, n * 8);
+	{
+		const size_t o = (size_t)y0 * f.W, m = (size_t)(y1 - y0) * f.W;
+		if (out->rgba8) memcpy((uint8_t*)out->rgba8 + o * 4, f.rgba + o * 4, m * 4);
+		if (out->tri_id) memcpy(out->tri_id + o, f.tri + o, m * 4);
+		if (out->depth_bits) memcpy(out->depth_bits + o, f.depth + o, m * 4);
+		if (out->mip_level) memcpy(out->mip_level + o, f.mip + o, m);
+		if (out->stencil) memcpy(out->stencil + o, f.stencil + o, m);
+		if (out->gbuf_normal) memcpy(out->gbuf_normal + o * 4, f.gN + o * 4, m * 8);
+		if (out->gbuf_albedo) memcpy(out->gbuf_albedo + o * 4, f.gA + o * 4, m * 8);
+	}
 	if (out->shadow_map && needShadow) memcpy(out->shadow_map, f.shadow, (size_t)f.S * f.S * 4);
 	free(f.depth); free(f.tri); free(f.rgba); free(f.mip); free(f.stencil); free(f.gN); free(f.gA); free(f.shadow);
 	return 0;
+}
+
+/* One whole frame. */
+ORA_API int ora_render(const ora_scene* sc, const vkr_frame_params* fp, const vkr_frame_out* out)
+{
+	return ora_render_rows(sc, fp, out, 0, fp->height);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -293,3 +293,18 @@ def test_mip_view_levels_and_derivative_view(micro_oracle):
     assert set(np.unique(m["mip_level"][cov])) - {0} and np.all(m["mip_level"][~cov] == 0xFF)
     d4 = render(micro_oracle, debug=4)
     assert np.all(d4["rgba8"][cov][:, 2] == 0) and np.all(d4["rgba8"][cov][:, 3] == 255)
+
+
+def test_banded_oracle_equals_whole_frame(micro, micro_oracle):
+    """ora_render_rows on concurrent threads (the multi-core CPU baseline) produces the frame ora_render does,
+    in every mode."""
+    from vulkanrenderer_amd import abi
+    from oracle import oracle
+    W, H = 96, 54
+    for kw in (dict(deferred=True), dict(debug=1), dict(debug=2), dict(debug=5), dict(debug=6), dict(mosaic=True)):
+        u = oracle.make_uniforms(W, H, pose_matrix(0.5, -0.3, -2.0, yaw=0.4, pitch=-0.15), kw.get("debug", 1))
+        p = abi.make_params(W, H, u, shadow_size=128, **kw)
+        a = micro_oracle.render(p)
+        b = micro_oracle.render(p, threads=4)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (kw, k)
