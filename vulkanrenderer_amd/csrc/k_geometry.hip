@@ -202,6 +202,7 @@ __device__ __forceinline__ bool tri_front(const SetupArgs& a, uint32_t t, TriFro
 	if ((c0.z > c0.w) & (c1.z > c1.w) & (c2.z > c2.w)) ok = false;
 	if (!ok) return false;
 	if (!vkr_tri_planes(c0, c1, c2, a.view.W, a.view.H, f.pl)) return false;
+	a.planes[t] = f.pl; // once per triangle instead of once per shaded pixel
 	const bool isAlphaMesh = t >= a.sc.nTriOpaque;
 	f.cull = isAlphaMesh ? a.cullAlpha : a.cullOpaque;
 	f.prim = a.useOrderB ? a.sc.orderB[t] : t;

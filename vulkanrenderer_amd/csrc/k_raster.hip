@@ -354,8 +354,8 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 					// alpha-tested passes submit in order A, so prim indexes sc.tri directly
 					const uint32_t i0 = a.sc.tri[3 * (size_t)s.prim + 0], i1 = a.sc.tri[3 * (size_t)s.prim + 1],
 					               i2 = a.sc.tri[3 * (size_t)s.prim + 2];
-					TriPlanes pl;
-					if (vkr_tri_planes<false>(a.clip[i0], a.clip[i1], a.clip[i2], a.view.W, a.view.H, pl)) {
+					const TriPlanes pl = a.planes[s.prim];
+					{
 						const uint32_t slot = atomicAdd(&sCount, 1u);
 						AlphaCover& c = sCov[slot];
 						EdgeSetup E;

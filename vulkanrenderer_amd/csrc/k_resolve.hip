@@ -1,7 +1,7 @@
 // k_resolve.hip — per-pixel shading off the visibility buffer.
 //
-// Each thread takes the (depth | primitive) key of one pixel, rebuilds the
-// triangle's interpolation planes from its clip-space vertices and runs the
+// Each thread takes the (depth | primitive) key of one pixel, fetches the
+// triangle's interpolation planes (computed by triangle setup) and runs the
 // fragment program of the pass exactly once per visible pixel:
 //   k_resolve_gbuf     gBufWrite.frag:16-27        (deferred geometry subpass)
 //   k_resolve_forward  default.frag:82-104         (forward pass incl. shadow lookup)
@@ -28,7 +28,7 @@ __device__ __forceinline__ bool load_frag(const ResolveArgs& a, int px, int py, 
 {
 	f.tA = tA;
 	f.i0 = a.sc.tri[3 * (size_t)tA + 0]; f.i1 = a.sc.tri[3 * (size_t)tA + 1]; f.i2 = a.sc.tri[3 * (size_t)tA + 2];
-	if (!vkr_tri_planes<NEEDZ>(a.clip[f.i0], a.clip[f.i1], a.clip[f.i2], a.view.W, a.view.H, f.pl)) return false;
+	f.pl = a.planes[tA]; // every visible triangle went through k_setup, which stored its planes
 	vkr_bary_at(f.pl, px, py, f.b);
 	float2 t0 = make_float2(a.sc.uv[2 * (size_t)f.i0], a.sc.uv[2 * (size_t)f.i0 + 1]);
 	float2 t1 = make_float2(a.sc.uv[2 * (size_t)f.i1], a.sc.uv[2 * (size_t)f.i1 + 1]);

@@ -96,7 +96,7 @@ struct vkr_context {
 	float* dThresh = nullptr; // 255
 	float hDecode[256], hThresh[255];
 	// geometry scratch
-	DevBuf clip, recs, recTiles, recLocal, clipQueue, counters, tileCount, tileCountA, tileCountBig, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
+	DevBuf clip, planes, recs, recTiles, recLocal, clipQueue, counters, tileCount, tileCountA, tileCountBig, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
 	uint32_t recCap = 0, binCap = 0;
 	double capScale = 1.0;
 	uint64_t binFloor = 0; // bin entries a pass has been seen to need (from an overflowed attempt)
@@ -318,7 +318,7 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf* bufs[] = { &c->clip, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->counters, &c->tileCount, &c->tileCountA, &c->tileCountBig, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
+	DevBuf* bufs[] = { &c->clip, &c->planes, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->counters, &c->tileCount, &c->tileCountA, &c->tileCountBig, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
 		&c->binKeys, &c->binList2, &c->binKeys2, &c->sortTemp, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
 		&c->colour2, &c->stencil, &c->mip, &c->shadow };
 	for (DevBuf* b : bufs) b->release();
@@ -669,6 +669,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	const uint32_t binCap = (uint32_t)std::min<double>(4.0e9, std::max<double>(((double)recCap * 3.0 + nTiles) * c->capScale, (double)c->binFloor));
 	int rc;
 	if ((rc = c->clip.ensure((size_t)s->dev.nVert * sizeof(float4)))) return rc;
+	if ((rc = c->planes.ensure((size_t)(s->dev.nTri ? s->dev.nTri : 1) * sizeof(TriPlanes)))) return rc;
 	if ((rc = c->recs.ensure((size_t)recCap * sizeof(SubTri)))) return rc;
 	if ((rc = c->recTiles.ensure((size_t)recCap * sizeof(uint2)))) return rc;
 	if ((rc = c->recLocal.ensure((size_t)recCap * 8 * 4))) return rc;
@@ -702,7 +703,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 		a.recs = c->recs.as<SubTri>(); a.recTiles = c->recTiles.as<uint2>(); a.recCap = recCap;
 		a.recCount = counters; a.tileCount = c->tileCount.as<uint32_t>(); a.overflow = counters + 1;
 		a.tileCountBig = c->tileCountBig.as<uint32_t>(); a.tileCountA = c->tileCountA.as<uint32_t>(); a.recLocal = c->recLocal.as<uint32_t>();
-		a.clipQueue = c->clipQueue.as<uint32_t>(); a.clipCount = counters + 3;
+		a.clipQueue = c->clipQueue.as<uint32_t>(); a.clipCount = counters + 3; a.planes = c->planes.as<TriPlanes>();
 		vkr_launch_setup(c->stream, a);
 	}
 	{
@@ -728,7 +729,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 
 static void fill_raster_args(vkr_context* c, const vkr_scene* s, const ViewDev& view, RasterArgs& r)
 {
-	r.sc = s->dev; r.view = view; r.clip = c->clip.as<float4>(); r.recs = c->recs.as<SubTri>();
+	r.sc = s->dev; r.view = view; r.clip = c->clip.as<float4>(); r.planes = c->planes.as<TriPlanes>(); r.recs = c->recs.as<SubTri>();
 	r.tileOffset = c->tileOffset.as<uint32_t>(); r.tileCount = c->tileCount.as<uint32_t>(); r.tileCountA = c->tileCountA.as<uint32_t>(); r.binList = c->binList.as<uint32_t>(); r.binCap = c->binCap;
 	r.vis = nullptr; r.depthOut = nullptr; r.countOut = nullptr;
 	r.alphaTiles = c->tileFlags.as<uint32_t>(); r.alphaTileCount = c->counters.as<uint32_t>() + 2; r.alphaPass = 0;
@@ -786,7 +787,7 @@ static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 		StageTimer t(c, ST_RESOLVE_FORWARD);
 		ResolveArgs a;
 		memset(&a, 0, sizeof a);
-		a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.vis = c->vis.as<unsigned long long>();
+		a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.planes = c->planes.as<TriPlanes>(); a.vis = c->vis.as<unsigned long long>();
 		a.depth = c->depth.as<float>(); a.triId = c->triId.as<uint32_t>(); a.colour = colourDst;
 		a.shadow = c->shadow.as<float>(); a.shadowSize = S;
 		static const float biasMat[16] = { 0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 1.0f, 0, 0.5f, 0.5f, 0, 1.0f }; // default.vert:46-50
@@ -845,7 +846,7 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 			StageTimer t(c, ST_RESOLVE_GBUF);
 			ResolveArgs a;
 			memset(&a, 0, sizeof a);
-			a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.vis = c->vis.as<unsigned long long>();
+			a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.planes = c->planes.as<TriPlanes>(); a.vis = c->vis.as<unsigned long long>();
 			a.gN = c->gN.as<uint2>(); a.gA = c->gA.as<uint2>(); a.depth = c->depth.as<float>(); a.triId = c->triId.as<uint32_t>();
 			vkr_launch_resolve_gbuf(c->stream, a);
 		}
@@ -947,7 +948,7 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 			StageTimer t(c, ST_RESOLVE_DEBUG);
 			ResolveArgs a;
 			memset(&a, 0, sizeof a);
-			a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.vis = c->vis.as<unsigned long long>();
+			a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.planes = c->planes.as<TriPlanes>(); a.vis = c->vis.as<unsigned long long>();
 			a.depth = c->depth.as<float>(); a.triId = c->triId.as<uint32_t>(); a.mip = c->mip.as<uint8_t>();
 			a.colour = c->colour.as<uint32_t>(); a.debugMode = u.debugUniforms.debug; a.useOrderB = 1;
 			vkr_launch_resolve_debug(c->stream, a);

@@ -21,6 +21,7 @@ struct SetupArgs {
 	uint32_t* tileCountBig; // entries of records touching more
 	uint32_t* recLocal;     // 8 per record slot: index inside each touched tile's bin (records touching <= 8 tiles)
 	uint32_t* overflow;
+	TriPlanes* planes;    // per triangle (order A index): interpolation + depth planes, for the resolve and alpha passes
 	uint32_t* clipQueue;  // triangles that need the polygon clipper (capacity: count)
 	uint32_t* clipCount;  // zeroed by the caller
 };
@@ -48,6 +49,7 @@ struct RasterArgs {
 	SceneDev sc;
 	ViewDev view;
 	const float4* clip;
+	const TriPlanes* planes;
 	const SubTri* recs;
 	const uint32_t* tileOffset;
 	const uint32_t* tileCount;  // a tile's bin holds tileCount entries without alpha test, then tileCountA alpha-tested
@@ -76,6 +78,7 @@ struct ResolveArgs {
 	SceneDev sc;
 	ViewDev view;
 	const float4* clip;
+	const TriPlanes* planes; // written by k_setup of the same pass
 	const unsigned long long* vis;
 	// deferred
 	uint2* gN; uint2* gA;
