@@ -84,18 +84,28 @@ __device__ __forceinline__ void fragment(unsigned long long* tb64, uint32_t* tb3
 	}
 }
 
-// Broadcasts lane `src`'s sub-triangle and its tile-clipped bounding box to the wave.
+// Broadcasts lane `src`'s sub-triangle and its tile-clipped bounding box to the wave.  `src` is wave-uniform, so
+// the values travel through v_readlane into scalar registers (no LDS permute).
+__device__ __forceinline__ int rl_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ double rl_d(double v, int src)
+{
+	const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src);
+	return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ void bcast_subtri(const SubTri& s, int bx0, int by0, int bx1, int by1, int src, SubTri& w, int& wx0,
                                              int& wy0, int& wx1, int& wy1)
 {
-	w.X0 = __shfl(s.X0, src, 64); w.Y0 = __shfl(s.Y0, src, 64);
-	w.X1 = __shfl(s.X1, src, 64); w.Y1 = __shfl(s.Y1, src, 64);
-	w.X2 = __shfl(s.X2, src, 64); w.Y2 = __shfl(s.Y2, src, 64);
-	w.prim = __shfl(s.prim, src, 64); w.flags = __shfl(s.flags, src, 64);
-	w.Az = __shfl(s.Az, src, 64); w.Bz = __shfl(s.Bz, src, 64); w.Cz = __shfl(s.Cz, src, 64);
-	w.bias = __shfl(s.bias, src, 64);
-	wx0 = __shfl(bx0, src, 64); wy0 = __shfl(by0, src, 64);
-	wx1 = __shfl(bx1, src, 64); wy1 = __shfl(by1, src, 64);
+	w.X0 = rl_i(s.X0, src); w.Y0 = rl_i(s.Y0, src);
+	w.X1 = rl_i(s.X1, src); w.Y1 = rl_i(s.Y1, src);
+	w.X2 = rl_i(s.X2, src); w.Y2 = rl_i(s.Y2, src);
+	w.prim = (uint32_t)rl_i((int)s.prim, src); w.flags = (uint32_t)rl_i((int)s.flags, src);
+	w.Az = rl_d(s.Az, src); w.Bz = rl_d(s.Bz, src); w.Cz = rl_d(s.Cz, src);
+	w.bias = rl_d(s.bias, src);
+	wx0 = rl_i(bx0, src); wy0 = rl_i(by0, src);
+	wx1 = rl_i(bx1, src); wy1 = rl_i(by1, src);
 }
 
 // Every sub-triangle of the tile's bin that needs no alpha test.  In
