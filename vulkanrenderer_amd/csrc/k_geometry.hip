@@ -10,9 +10,12 @@
 #include "vkr_kernels.h"
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_xform(const float* __restrict__ pos, float4* __restrict__ clip, uint32_t nVert, Mat4 M)
+// Also zeroes the pass's counters (the kernels after it accumulate into them), which saves four fill launches.
+__global__ __launch_bounds__(256) void k_xform(const float* __restrict__ pos, float4* __restrict__ clip, uint32_t nVert, Mat4 M, ZeroArgs zr)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	for (uint32_t i = v; i < zr.nTiles; i += gridDim.x * blockDim.x) { zr.tiles0[i] = 0u; zr.tiles1[i] = 0u; zr.tiles2[i] = 0u; }
+	if (v < 16u) zr.counters[v] = 0u;
 	if (v >= nVert) return;
 	float x = pos[3 * (size_t)v + 0], y = pos[3 * (size_t)v + 1], z = pos[3 * (size_t)v + 2];
 	clip[v] = vkr_xform(M, x, y, z);
@@ -315,8 +318,8 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 	while (bmask) {
 		const int src = __ffsll((long long)bmask) - 1;
 		bmask &= bmask - 1;
-		const uint32_t wx0 = __shfl(tx0, src, 64), wy0 = __shfl(ty0, src, 64);
-		const uint32_t wx1 = __shfl(tx1, src, 64), wy1 = __shfl(ty1, src, 64);
+		const uint32_t wx0 = (uint32_t)__builtin_amdgcn_readlane((int)tx0, src), wy0 = (uint32_t)__builtin_amdgcn_readlane((int)ty0, src);
+		const uint32_t wx1 = (uint32_t)__builtin_amdgcn_readlane((int)tx1, src), wy1 = (uint32_t)__builtin_amdgcn_readlane((int)ty1, src);
 		const uint32_t w = wx1 - wx0 + 1, cnt = w * (wy1 - wy0 + 1);
 		for (uint32_t k = lane; k < cnt; k += 64) atomicAdd(&a.tileCountBig[(wy0 + k / w) * a.view.tilesX + (wx0 + k % w)], 1u);
 	}
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(64) void k_setup_clip(SetupArgs a)
 __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ count, const uint32_t* __restrict__ countA,
                                                       const uint32_t* __restrict__ countBig,
                                                       uint32_t* __restrict__ offset, uint32_t* __restrict__ cursor, uint32_t nTiles,
-                                                      uint32_t cap, uint32_t* overflow)
+                                                      uint32_t cap, uint32_t* overflow, uint32_t* statusOut)
 {
 	__shared__ uint32_t wsum[16];
 	__shared__ uint32_t carry;
@@ -370,6 +373,11 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 	if (tid == 0) {
 		offset[nTiles] = carry;
 		if (carry > cap) atomicOr(overflow, 2u);
+		// status of the pass (appended records, overflow bits, bin entries needed), written where the host reads it
+		// after the stream is synchronised: pinned host memory, no copy commands
+		statusOut[0] = overflow[-1];
+		statusOut[1] = overflow[0] | (carry > cap ? 2u : 0u);
+		statusOut[2] = carry;
 	}
 }
 
@@ -411,9 +419,9 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 	while (mask) {
 		const int src = __ffsll((long long)mask) - 1;
 		mask &= mask - 1;
-		const uint32_t wr = __shfl(r, src, 64), wkey = __shfl(key, src, 64);
-		const uint32_t wx0 = __shfl(tx0, src, 64), wy0 = __shfl(ty0, src, 64);
-		const uint32_t wx1 = __shfl(tx1, src, 64), wy1 = __shfl(ty1, src, 64);
+		const uint32_t wr = (uint32_t)__builtin_amdgcn_readlane((int)r, src), wkey = (uint32_t)__builtin_amdgcn_readlane((int)key, src);
+		const uint32_t wx0 = (uint32_t)__builtin_amdgcn_readlane((int)tx0, src), wy0 = (uint32_t)__builtin_amdgcn_readlane((int)ty0, src);
+		const uint32_t wx1 = (uint32_t)__builtin_amdgcn_readlane((int)tx1, src), wy1 = (uint32_t)__builtin_amdgcn_readlane((int)ty1, src);
 		const uint32_t w = wx1 - wx0 + 1, cnt = w * (wy1 - wy0 + 1);
 		for (uint32_t k = lane; k < cnt; k += 64) {
 			const uint32_t tile = (wy0 + k / w) * a.tilesX + (wx0 + k % w);
@@ -428,10 +436,10 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 }
 
 // ---------------------------------------------------------------------------
-void vkr_launch_xform(hipStream_t s, const float* pos, float4* clip, uint32_t nVert, const Mat4& M)
+void vkr_launch_xform(hipStream_t s, const float* pos, float4* clip, uint32_t nVert, const Mat4& M, const ZeroArgs& z)
 {
-	if (!nVert) return;
-	hipLaunchKernelGGL(k_xform, dim3((nVert + 255) / 256), dim3(256), 0, s, pos, clip, nVert, M);
+	// at least one workgroup, so that the counters are zeroed for an empty scene too
+	hipLaunchKernelGGL(k_xform, dim3(nVert ? (nVert + 255) / 256 : 1), dim3(256), 0, s, pos, clip, nVert, M, z);
 }
 
 void vkr_launch_setup(hipStream_t s, const SetupArgs& a)
@@ -443,9 +451,9 @@ void vkr_launch_setup(hipStream_t s, const SetupArgs& a)
 }
 
 void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countA, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
-                           uint32_t nTiles, uint32_t cap, uint32_t* overflow)
+                           uint32_t nTiles, uint32_t cap, uint32_t* overflow, uint32_t* statusOut)
 {
-	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, count, countA, countBig, offset, cursor, nTiles, cap, overflow);
+	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, count, countA, countBig, offset, cursor, nTiles, cap, overflow, statusOut);
 }
 
 void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs)

@@ -685,13 +685,12 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if (g.keys && (rc = c->binKeys.ensure((size_t)binCap * 4))) return rc;
 	c->recCap = recCap; c->binCap = binCap;
 	uint32_t* counters = c->counters.as<uint32_t>(); // [0] recCount, [1] overflow, [2] alpha tile count, [3] clip queue length
-	HIP_CHECK(hipMemsetAsync(counters, 0, 64, c->stream));
-	HIP_CHECK(hipMemsetAsync(c->tileCount.p, 0, (size_t)nTiles * 4, c->stream));
-	HIP_CHECK(hipMemsetAsync(c->tileCountBig.p, 0, (size_t)nTiles * 4, c->stream));
-	HIP_CHECK(hipMemsetAsync(c->tileCountA.p, 0, (size_t)nTiles * 4, c->stream));
+	ZeroArgs z;
+	z.counters = counters; z.tiles0 = c->tileCount.as<uint32_t>(); z.tiles1 = c->tileCountA.as<uint32_t>();
+	z.tiles2 = c->tileCountBig.as<uint32_t>(); z.nTiles = nTiles;
 	{
 		StageTimer t(c, ST_XFORM);
-		vkr_launch_xform(c->stream, s->dev.pos, c->clip.as<float4>(), s->dev.nVert, g.M);
+		vkr_launch_xform(c->stream, s->dev.pos, c->clip.as<float4>(), s->dev.nVert, g.M, z);
 	}
 	{
 		StageTimer t(c, ST_SETUP);
@@ -709,7 +708,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	{
 		StageTimer t(c, ST_BIN_SCAN);
 		vkr_launch_scan_tiles(c->stream, c->tileCount.as<uint32_t>(), c->tileCountA.as<uint32_t>(), c->tileCountBig.as<uint32_t>(), c->tileOffset.as<uint32_t>(), c->cursor.as<uint32_t>(), nTiles,
-		                      binCap, counters + 1);
+		                      binCap, counters + 1, &c->hStatus[statusSlot].recCount);
 	}
 	{
 		StageTimer t(c, ST_BIN_FILL);
@@ -720,9 +719,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 		vkr_launch_bin_fill(c->stream, b, recCap);
 	}
 	// status for the overflow check at vkr_wait
-	PassStatus* st = &c->hStatus[statusSlot];
-	HIP_CHECK(hipMemcpyAsync(&st->recCount, counters, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_CHECK(hipMemcpyAsync(&st->binTotal, c->tileOffset.as<uint32_t>() + nTiles, 4, hipMemcpyDeviceToHost, c->stream));
+	// (the pass's status for the overflow check at vkr_wait is written by k_scan_tiles into pinned host memory)
 	HIP_CHECK(hipGetLastError());
 	return VKR_OK;
 }
@@ -820,7 +817,22 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 	const ViewDev view = make_view(fp.width, fp.height, x0, y0, x1, y1);
 	const size_t n = (size_t)(x1 - x0) * (y1 - y0);
 	int rc;
-	if ((rc = c->colour.ensure(n * 4))) return rc;
+	// The presented image is written straight into the caller's buffer when that is memory of this GPU
+	// (a 33 MB device-to-device copy per 4K frame otherwise); host buffers get a copy from the context's own.
+	uint32_t* colourDst = nullptr;
+	if (out.rgba8 && ((uintptr_t)out.rgba8 & 3u) == 0) {
+		hipPointerAttribute_t attr;
+		if (hipPointerGetAttributes(&attr, out.rgba8) == hipSuccess && attr.type == hipMemoryTypeDevice && attr.device == c->device)
+			colourDst = (uint32_t*)out.rgba8;
+		else
+			(void)hipGetLastError(); // an ordinary host pointer is not an error
+	}
+	const bool colourDirect = colourDst != nullptr;
+	if (!colourDirect) {
+		if ((rc = c->colour.ensure(n * 4))) return rc;
+		colourDst = c->colour.as<uint32_t>();
+	}
+	void* const rgbaCopy = colourDirect ? nullptr : out.rgba8; // copy_out skips a NULL destination
 	const int dbg = fp.debugVisualisation;
 	*nPasses = 0;
 
@@ -855,7 +867,7 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 			LightArgs l;
 			memset(&l, 0, sizeof l);
 			l.view = view; l.gN = c->gN.as<uint2>(); l.gA = c->gA.as<uint2>(); l.depth = c->depth.as<float>();
-			l.colour = c->colour.as<uint32_t>(); l.srgbThresh = c->dThresh;
+			l.colour = colourDst; l.srgbThresh = c->dThresh;
 			float invCam[16], invProj[16];
 			mat4_inverse(u.sceneUniforms.camera, invCam);
 			mat4_inverse(u.sceneUniforms.projection, invProj);
@@ -871,15 +883,15 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 			vkr_launch_deferred_light(c->stream, l);
 		}
 		StageTimer t(c, ST_COPY_OUT);
-		if ((rc = copy_out(c, out.rgba8, c->colour.p, n * 4)) || (rc = copy_out(c, out.tri_id, c->triId.p, n * 4)) ||
+		if ((rc = copy_out(c, rgbaCopy, c->colour.p, n * 4)) || (rc = copy_out(c, out.tri_id, c->triId.p, n * 4)) ||
 		    (rc = copy_out(c, out.depth_bits, c->depth.p, n * 4)) || (rc = copy_out(c, out.gbuf_normal, c->gN.p, n * 8)) ||
 		    (rc = copy_out(c, out.gbuf_albedo, c->gA.p, n * 8))) return rc;
 	} else if (!fp.mosaicEffect && dbg == 1) {
 		// ---- forward + shadow map (main/main.cpp:3948-4079)
-		if ((rc = run_forward(c, s, fp, view, c->colour.as<uint32_t>(), statusSlot, &out, true))) return rc;
+		if ((rc = run_forward(c, s, fp, view, colourDst, statusSlot, &out, true))) return rc;
 		*nPasses = 2;
 		StageTimer t(c, ST_COPY_OUT);
-		if ((rc = copy_out(c, out.rgba8, c->colour.p, n * 4))) return rc;
+		if ((rc = copy_out(c, rgbaCopy, c->colour.p, n * 4))) return rc;
 	} else if (!fp.mosaicEffect && (dbg == 5 || dbg == 6)) {
 		// ---- overdraw / overshading counters (main/main.cpp:4081-4136): every mesh in file order, cull BACK
 		if ((rc = c->stencil.ensure(n)) || (rc = c->depth.ensure(n * 4))) return rc;
@@ -923,10 +935,10 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 		}
 		{
 			StageTimer t(c, ST_OVERVIS_COLOUR);
-			vkr_launch_overvis_colour(c->stream, c->stencil.as<uint8_t>(), c->colour.as<uint32_t>(), c->dThresh, (uint32_t)n);
+			vkr_launch_overvis_colour(c->stream, c->stencil.as<uint8_t>(), colourDst, c->dThresh, (uint32_t)n);
 		}
 		StageTimer t(c, ST_COPY_OUT);
-		if ((rc = copy_out(c, out.rgba8, c->colour.p, n * 4)) || (rc = copy_out(c, out.stencil, c->stencil.p, n)) ||
+		if ((rc = copy_out(c, rgbaCopy, c->colour.p, n * 4)) || (rc = copy_out(c, out.stencil, c->stencil.p, n)) ||
 		    (rc = copy_out(c, out.depth_bits, c->depth.p, n * 4))) return rc;
 	} else if (!fp.mosaicEffect) {
 		// ---- debug views 2/3/4 (main/main.cpp:4138-4193): every mesh in file order, cull BACK, no discard
@@ -950,11 +962,11 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 			memset(&a, 0, sizeof a);
 			a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.planes = c->planes.as<TriPlanes>(); a.vis = c->vis.as<unsigned long long>();
 			a.depth = c->depth.as<float>(); a.triId = c->triId.as<uint32_t>(); a.mip = c->mip.as<uint8_t>();
-			a.colour = c->colour.as<uint32_t>(); a.debugMode = u.debugUniforms.debug; a.useOrderB = 1;
+			a.colour = colourDst; a.debugMode = u.debugUniforms.debug; a.useOrderB = 1;
 			vkr_launch_resolve_debug(c->stream, a);
 		}
 		StageTimer t(c, ST_COPY_OUT);
-		if ((rc = copy_out(c, out.rgba8, c->colour.p, n * 4)) || (rc = copy_out(c, out.tri_id, c->triId.p, n * 4)) ||
+		if ((rc = copy_out(c, rgbaCopy, c->colour.p, n * 4)) || (rc = copy_out(c, out.tri_id, c->triId.p, n * 4)) ||
 		    (rc = copy_out(c, out.depth_bits, c->depth.p, n * 4)) || (rc = copy_out(c, out.mip_level, c->mip.p, n))) return rc;
 	} else {
 		// ---- mosaic (main/main.cpp:4195-4320): forward pass into the offscreen sRGB image, then the
@@ -971,11 +983,11 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 		*nPasses = 2;
 		{
 			StageTimer t(c, ST_MOSAIC);
-			vkr_launch_mosaic(c->stream, c->colour2.as<uint32_t>(), hx0, hy0, hx1 - hx0, hy1 - hy0, c->colour.as<uint32_t>(), view,
+			vkr_launch_mosaic(c->stream, c->colour2.as<uint32_t>(), hx0, hy0, hx1 - hx0, hy1 - hy0, colourDst, view,
 			                  c->dDecode, c->dThresh);
 		}
 		StageTimer t(c, ST_COPY_OUT);
-		if ((rc = copy_out(c, out.rgba8, c->colour.p, n * 4))) return rc;
+		if ((rc = copy_out(c, rgbaCopy, c->colour.p, n * 4))) return rc;
 	}
 	HIP_CHECK(hipGetLastError());
 	return VKR_OK;

@@ -2,6 +2,13 @@
 #pragma once
 #include "vkr_device.h"
 
+// counters k_xform zeroes for the kernels after it: 16 scalar counters and three per-tile arrays
+struct ZeroArgs {
+	uint32_t* counters;
+	uint32_t* tiles0; uint32_t* tiles1; uint32_t* tiles2;
+	uint32_t nTiles;
+};
+
 struct SetupArgs {
 	SceneDev sc;
 	ViewDev view;
@@ -102,10 +109,10 @@ struct LightArgs {
 	uint32_t clearColour; // packed RGBA8 of the render pass clear value
 };
 
-void vkr_launch_xform(hipStream_t s, const float* pos, float4* clip, uint32_t nVert, const Mat4& M);
+void vkr_launch_xform(hipStream_t s, const float* pos, float4* clip, uint32_t nVert, const Mat4& M, const ZeroArgs& z);
 void vkr_launch_setup(hipStream_t s, const SetupArgs& a);
 void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countA, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
-                           uint32_t nTiles, uint32_t cap, uint32_t* overflow);
+                           uint32_t nTiles, uint32_t cap, uint32_t* overflow, uint32_t* statusOut);
 void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs);
 void vkr_launch_raster(hipStream_t s, int mode, const RasterArgs& a);
 void vkr_launch_overshade(hipStream_t s, const OvershadeArgs& a);
