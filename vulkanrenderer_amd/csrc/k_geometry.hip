@@ -148,6 +148,7 @@ __device__ __forceinline__ bool commit_subtri(const SetupArgs& a, uint32_t slot,
 	if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 8) { count_small(a, slot, tiles, (r.flags & VKR_ST_ALPHA) != 0); return true; }
 	for (uint32_t ty = ty0; ty <= ty1; ty++)
 		for (uint32_t tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tileCountBig[ty * a.view.tilesX + tx], 1u);
+	a.bigQueue[atomicAdd(a.bigCount, 1u)] = slot;
 	return true;
 }
 
@@ -313,8 +314,17 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 				}
 			}
 	}
-	// records that touch many tiles: the wave counts them together
+	// records that touch many tiles: queued for k_bin_fill_big (one wavefront per record; they come in runs - the
+	// near-field triangles of a mesh - and would otherwise pile up in a few wavefronts of the fill pass) ...
 	unsigned long long bmask = __ballot(nt > 8);
+	if (bmask) {
+		const int leader = __ffsll((long long)bmask) - 1;
+		uint32_t base = 0;
+		if ((int)lane == leader) base = atomicAdd(a.bigCount, (uint32_t)__popcll(bmask));
+		base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+		if (nt > 8) a.bigQueue[base + (uint32_t)__popcll(bmask & ((1ull << lane) - 1ull))] = slot;
+	}
+	// ... and counted here, the wave together
 	while (bmask) {
 		const int src = __ffsll((long long)bmask) - 1;
 		bmask &= bmask - 1;
@@ -414,22 +424,27 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 				}
 			}
 	}
-	unsigned long long mask = __ballot(big);
+}
+
+// The records that touch more than 8 tiles, one wavefront per record (lanes over its tiles); their entries go behind
+// the others' in each tile's bin, positions from a cursor.
+__global__ __launch_bounds__(256) void k_bin_fill_big(BinFillArgs a)
+{
 	const uint32_t lane = threadIdx.x & 63;
-	while (mask) {
-		const int src = __ffsll((long long)mask) - 1;
-		mask &= mask - 1;
-		const uint32_t wr = (uint32_t)__builtin_amdgcn_readlane((int)r, src), wkey = (uint32_t)__builtin_amdgcn_readlane((int)key, src);
-		const uint32_t wx0 = (uint32_t)__builtin_amdgcn_readlane((int)tx0, src), wy0 = (uint32_t)__builtin_amdgcn_readlane((int)ty0, src);
-		const uint32_t wx1 = (uint32_t)__builtin_amdgcn_readlane((int)tx1, src), wy1 = (uint32_t)__builtin_amdgcn_readlane((int)ty1, src);
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t n = min(*a.bigCount, a.recCap);
+	for (uint32_t q = wave; q < n; q += nWaves) {
+		const uint32_t r = a.bigQueue[q];
+		const uint2 tr = a.recTiles[r];
+		const uint32_t wx0 = tr.x & 0xffffu, wy0 = tr.x >> 16, wx1 = tr.y & 0xffffu, wy1 = (tr.y >> 16) & 0x7fffu;
+		const uint32_t key = a.keys ? a.recs[r].prim : 0u;
 		const uint32_t w = wx1 - wx0 + 1, cnt = w * (wy1 - wy0 + 1);
 		for (uint32_t k = lane; k < cnt; k += 64) {
 			const uint32_t tile = (wy0 + k / w) * a.tilesX + (wx0 + k % w);
-			// behind the entries of the records whose positions the counting pass fixed
 			const uint32_t idx = a.tileOffset[tile] + a.tileCount[tile] + a.tileCountA[tile] + atomicAdd(&a.cursor[tile], 1u);
 			if (idx < a.binCap) {
-				a.binList[idx] = wr;
-				if (a.keys) a.keys[idx] = wkey;
+				a.binList[idx] = r;
+				if (a.keys) a.keys[idx] = key;
 			}
 		}
 	}
@@ -460,4 +475,5 @@ void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs)
 {
 	if (!maxRecs) return;
 	hipLaunchKernelGGL(k_bin_fill, dim3((maxRecs + 255) / 256), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_bin_fill_big, dim3(256), dim3(256), 0, s, a);
 }

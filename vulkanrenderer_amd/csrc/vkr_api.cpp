@@ -96,7 +96,7 @@ struct vkr_context {
 	float* dThresh = nullptr; // 255
 	float hDecode[256], hThresh[255];
 	// geometry scratch
-	DevBuf clip, planes, recs, recTiles, recLocal, clipQueue, counters, tileCount, tileCountA, tileCountBig, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
+	DevBuf clip, planes, recs, recTiles, recLocal, clipQueue, bigQueue, counters, tileCount, tileCountA, tileCountBig, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
 	uint32_t recCap = 0, binCap = 0;
 	double capScale = 1.0;
 	uint64_t binFloor = 0; // bin entries a pass has been seen to need (from an overflowed attempt)
@@ -318,7 +318,7 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf* bufs[] = { &c->clip, &c->planes, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->counters, &c->tileCount, &c->tileCountA, &c->tileCountBig, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
+	DevBuf* bufs[] = { &c->clip, &c->planes, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->bigQueue, &c->counters, &c->tileCount, &c->tileCountA, &c->tileCountBig, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
 		&c->binKeys, &c->binList2, &c->binKeys2, &c->sortTemp, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
 		&c->colour2, &c->stencil, &c->mip, &c->shadow };
 	for (DevBuf* b : bufs) b->release();
@@ -673,6 +673,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if ((rc = c->recs.ensure((size_t)recCap * sizeof(SubTri)))) return rc;
 	if ((rc = c->recTiles.ensure((size_t)recCap * sizeof(uint2)))) return rc;
 	if ((rc = c->recLocal.ensure((size_t)recCap * 8 * 4))) return rc;
+	if ((rc = c->bigQueue.ensure((size_t)recCap * 4))) return rc;
 	if ((rc = c->clipQueue.ensure((size_t)(g.count ? g.count : 1) * 4))) return rc;
 	if ((rc = c->counters.ensure(64))) return rc;
 	if ((rc = c->tileCount.ensure((size_t)nTiles * 4))) return rc;
@@ -684,7 +685,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if ((rc = c->binList.ensure((size_t)binCap * 4))) return rc;
 	if (g.keys && (rc = c->binKeys.ensure((size_t)binCap * 4))) return rc;
 	c->recCap = recCap; c->binCap = binCap;
-	uint32_t* counters = c->counters.as<uint32_t>(); // [0] recCount, [1] overflow, [2] alpha tile count, [3] clip queue length
+	uint32_t* counters = c->counters.as<uint32_t>(); // [0] recCount, [1] overflow, [2] alpha tile count, [3] clip queue length, [4] big-record queue length
 	ZeroArgs z;
 	z.counters = counters; z.tiles0 = c->tileCount.as<uint32_t>(); z.tiles1 = c->tileCountA.as<uint32_t>();
 	z.tiles2 = c->tileCountBig.as<uint32_t>(); z.nTiles = nTiles;
@@ -702,7 +703,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 		a.recs = c->recs.as<SubTri>(); a.recTiles = c->recTiles.as<uint2>(); a.recCap = recCap;
 		a.recCount = counters; a.tileCount = c->tileCount.as<uint32_t>(); a.overflow = counters + 1;
 		a.tileCountBig = c->tileCountBig.as<uint32_t>(); a.tileCountA = c->tileCountA.as<uint32_t>(); a.recLocal = c->recLocal.as<uint32_t>();
-		a.clipQueue = c->clipQueue.as<uint32_t>(); a.clipCount = counters + 3; a.planes = c->planes.as<TriPlanes>();
+		a.clipQueue = c->clipQueue.as<uint32_t>(); a.clipCount = counters + 3; a.bigQueue = c->bigQueue.as<uint32_t>(); a.bigCount = counters + 4; a.planes = c->planes.as<TriPlanes>();
 		vkr_launch_setup(c->stream, a);
 	}
 	{
@@ -714,7 +715,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 		StageTimer t(c, ST_BIN_FILL);
 		BinFillArgs b;
 		b.recs = c->recs.as<SubTri>(); b.recTiles = c->recTiles.as<uint2>(); b.recCount = counters; b.baseCount = g.count; b.recCap = recCap;
-		b.tileOffset = c->tileOffset.as<uint32_t>(); b.tileCount = c->tileCount.as<uint32_t>(); b.tileCountA = c->tileCountA.as<uint32_t>(); b.recLocal = c->recLocal.as<uint32_t>(); b.cursor = c->cursor.as<uint32_t>(); b.binList = c->binList.as<uint32_t>();
+		b.tileOffset = c->tileOffset.as<uint32_t>(); b.tileCount = c->tileCount.as<uint32_t>(); b.tileCountA = c->tileCountA.as<uint32_t>(); b.recLocal = c->recLocal.as<uint32_t>(); b.bigQueue = c->bigQueue.as<uint32_t>(); b.bigCount = counters + 4; b.cursor = c->cursor.as<uint32_t>(); b.binList = c->binList.as<uint32_t>();
 		b.keys = g.keys ? c->binKeys.as<uint32_t>() : nullptr; b.binCap = binCap; b.tilesX = g.view.tilesX;
 		vkr_launch_bin_fill(c->stream, b, recCap);
 	}

@@ -29,6 +29,8 @@ struct SetupArgs {
 	uint32_t* recLocal;     // 8 per record slot: index inside each touched tile's bin (records touching <= 8 tiles)
 	uint32_t* overflow;
 	TriPlanes* planes;    // per triangle (order A index): interpolation + depth planes, for the resolve and alpha passes
+	uint32_t* bigQueue;   // record slots that touch more than 8 tiles (capacity: recCap)
+	uint32_t* bigCount;   // zeroed by the caller
 	uint32_t* clipQueue;  // triangles that need the polygon clipper (capacity: count)
 	uint32_t* clipCount;  // zeroed by the caller
 };
@@ -43,6 +45,8 @@ struct BinFillArgs {
 	const uint32_t* tileCount; // entries per tile fixed by the counting pass (no alpha test / alpha-tested)
 	const uint32_t* tileCountA;
 	const uint32_t* recLocal;
+	const uint32_t* bigQueue; // record slots that touch more than 8 tiles
+	const uint32_t* bigCount;
 	uint32_t* cursor;
 	uint32_t* binList;
 	uint32_t* keys; // optional: prim per entry (ordered passes)
