@@ -146,9 +146,7 @@ __device__ __forceinline__ bool commit_subtri(const SetupArgs& a, uint32_t slot,
 	a.recTiles[slot] = make_uint2(tiles.x, tiles.y | ((r.flags & VKR_ST_ALPHA) ? 0x80000000u : 0u));
 	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
 	if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 8) { count_small(a, slot, tiles, (r.flags & VKR_ST_ALPHA) != 0); return true; }
-	for (uint32_t ty = ty0; ty <= ty1; ty++)
-		for (uint32_t tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tileCountBig[ty * a.view.tilesX + tx], 1u);
-	a.bigQueue[atomicAdd(a.bigCount, 1u)] = slot;
+	a.bigQueue[atomicAdd(a.bigCount, 1u)] = slot; // counted by k_count_big
 	return true;
 }
 
@@ -314,8 +312,8 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 				}
 			}
 	}
-	// records that touch many tiles: queued for k_bin_fill_big (one wavefront per record; they come in runs - the
-	// near-field triangles of a mesh - and would otherwise pile up in a few wavefronts of the fill pass) ...
+	// records that touch many tiles: queued for k_count_big / k_bin_fill_big (one wavefront per record; they come in
+	// runs - the near-field triangles of a mesh - and would otherwise pile up in a few wavefronts)
 	unsigned long long bmask = __ballot(nt > 8);
 	if (bmask) {
 		const int leader = __ffsll((long long)bmask) - 1;
@@ -323,15 +321,6 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 		if ((int)lane == leader) base = atomicAdd(a.bigCount, (uint32_t)__popcll(bmask));
 		base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
 		if (nt > 8) a.bigQueue[base + (uint32_t)__popcll(bmask & ((1ull << lane) - 1ull))] = slot;
-	}
-	// ... and counted here, the wave together
-	while (bmask) {
-		const int src = __ffsll((long long)bmask) - 1;
-		bmask &= bmask - 1;
-		const uint32_t wx0 = (uint32_t)__builtin_amdgcn_readlane((int)tx0, src), wy0 = (uint32_t)__builtin_amdgcn_readlane((int)ty0, src);
-		const uint32_t wx1 = (uint32_t)__builtin_amdgcn_readlane((int)tx1, src), wy1 = (uint32_t)__builtin_amdgcn_readlane((int)ty1, src);
-		const uint32_t w = wx1 - wx0 + 1, cnt = w * (wy1 - wy0 + 1);
-		for (uint32_t k = lane; k < cnt; k += 64) atomicAdd(&a.tileCountBig[(wy0 + k / w) * a.view.tilesX + (wx0 + k % w)], 1u);
 	}
 }
 
@@ -345,6 +334,20 @@ __global__ __launch_bounds__(64) void k_setup_clip(SetupArgs a)
 		if (!tri_front(a, t, f)) continue;
 		const double hW = (double)a.view.W * 0.5, hH = (double)a.view.H * 0.5;
 		setup_clipped(a, f.c0, f.c1, f.c2, f.pl, f.prim, f.flags, f.cull, hW, hH);
+	}
+}
+
+// Counts the queued many-tile records into tileCountBig, one wavefront per record.
+__global__ __launch_bounds__(256) void k_count_big(SetupArgs a)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t n = min(*a.bigCount, a.recCap);
+	for (uint32_t q = wave; q < n; q += nWaves) {
+		const uint2 tr = a.recTiles[a.bigQueue[q]];
+		const uint32_t wx0 = tr.x & 0xffffu, wy0 = tr.x >> 16, wx1 = tr.y & 0xffffu, wy1 = (tr.y >> 16) & 0x7fffu;
+		const uint32_t w = wx1 - wx0 + 1, cnt = w * (wy1 - wy0 + 1);
+		for (uint32_t k = lane; k < cnt; k += 64) atomicAdd(&a.tileCountBig[(wy0 + k / w) * a.view.tilesX + (wx0 + k % w)], 1u);
 	}
 }
 
@@ -463,6 +466,7 @@ void vkr_launch_setup(hipStream_t s, const SetupArgs& a)
 	hipLaunchKernelGGL(k_setup, dim3((a.count + 255) / 256), dim3(256), 0, s, a);
 	// few triangles need the clipper; a fixed grid strides over however many were queued
 	hipLaunchKernelGGL(k_setup_clip, dim3(512), dim3(64), 0, s, a);
+	hipLaunchKernelGGL(k_count_big, dim3(256), dim3(256), 0, s, a);
 }
 
 void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countA, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
