@@ -60,6 +60,25 @@ def measured_traffic(width, height, kernel="k_deferred_light"):
     return best
 
 
+def measured_valu_busy(width, height, kernel="k_deferred_light"):
+    """Vector-ALU busy fraction of `kernel` from the newest committed PMC summary (profiles/*pmc_valu*.json) taken at this
+    extent, or None: the lighting kernel is bound by ALU issue, so this is reported beside the HBM fraction."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_valu*.json"))):
+        try:
+            with open(path) as f:
+                j = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if j.get("width") != width or j.get("height") != height:
+            continue
+        for name, k in j.get("kernels", {}).items():
+            if name.startswith(kernel) and "valu_busy_frac" in k:
+                best = (min(1.0, float(k["valu_busy_frac"])), os.path.basename(path))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +194,10 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic[0] if traffic else None,
                     "traffic_source": ("profiles/" + traffic[1]) if traffic else None, "kernel": "k_deferred_light",
                     "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": LIGHT_BYTES_PER_PIXEL * launch_pixels}
+        valu = measured_valu_busy(W, rh) if args.mode == "deferred" else None
+        if valu:
+            roofline["valu_busy_frac"] = valu[0]
+            roofline["valu_busy_source"] = "profiles/" + valu[1]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
