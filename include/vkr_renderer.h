@@ -184,6 +184,10 @@ VKR_API void vkr_scene_destroy(vkr_scene* scene);
  * allocated by the library; release it with vkr_free(). */
 VKR_API int vkr_decode_png_file(const char* path, uint8_t** rgba8, uint32_t* width, uint32_t* height);
 VKR_API void vkr_free(void* p);
+/* Host-only: writes a frame (tightly packed R8G8B8A8, as vkr_render delivers it) as a PNG file.  The reference only
+ * presents to the swapchain (vkQueuePresentKHR, main/main.cpp:1391-1405); this is the way out for a headless host.
+ * flip: 0 = row 0 is the top row (vkr_render's order), 1 = row 0 is the bottom row (vkr_decode_png_file's order). */
+VKR_API int vkr_write_png_file(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height, int flip);
 /* number of triangles / vertices held by the scene */
 VKR_API int vkr_scene_stats(const vkr_scene* scene, uint64_t* triangles, uint64_t* vertices, uint64_t* texture_bytes);
 /* Reads mip level `level` of texture `tex` back (RGBA8); for parity tests of

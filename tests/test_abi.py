@@ -60,3 +60,17 @@ def test_no_device_is_an_error_not_a_fallback():
     assert not h.value
     with pytest.raises(renderer.VkrError):
         renderer.Context(0)
+
+
+def test_png_write_then_decode_roundtrip(tmp_path):
+    """vkr_write_png_file -> vkr_decode_png_file gives the pixels back (the decoder returns rows bottom first)."""
+    import numpy as np
+    from vulkanrenderer_amd import renderer
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    p = str(tmp_path / "frame.png")
+    renderer.write_png(p, img)
+    back = renderer.decode_png(p)
+    assert np.array_equal(back[::-1], img)
+    renderer.write_png(p, img, flip=True)
+    assert np.array_equal(renderer.decode_png(p), img)

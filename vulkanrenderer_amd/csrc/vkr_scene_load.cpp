@@ -177,6 +177,47 @@ extern "C" int vkr_decode_png_file(const char* path, uint8_t** rgba8, uint32_t* 
 
 extern "C" void vkr_free(void* p) { free(p); }
 
+// A frame as an 8-bit RGBA PNG (filter 0 on every row, zlib level 6).  Rows are written top first, the order
+// vkr_render delivers them in; flip = 1 writes them bottom first (the order vkr_decode_png_file returns).
+extern "C" int vkr_write_png_file(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height, int flip)
+{
+	if (!path || !rgba8 || !width || !height) return vkr_set_error_ext(VKR_E_INVALID, "vkr_write_png_file: NULL argument or empty image");
+	const size_t stride = (size_t)width * 4;
+	std::vector<uint8_t> raw((stride + 1) * height);
+	for (uint32_t y = 0; y < height; y++) {
+		const uint32_t sy = flip ? height - 1 - y : y;
+		raw[(stride + 1) * y] = 0; // filter type None
+		memcpy(&raw[(stride + 1) * y + 1], rgba8 + stride * sy, stride);
+	}
+	uLongf zn = compressBound((uLong)raw.size());
+	std::vector<uint8_t> z(zn);
+	if (compress2(z.data(), &zn, raw.data(), (uLong)raw.size(), 6) != Z_OK) return vkr_set_error_ext(VKR_E_NOMEM, "%s: deflate failed", path);
+	FILE* f = fopen(path, "wb");
+	if (!f) return vkr_set_error_ext(VKR_E_IO, "%s: cannot open for writing", path);
+	auto be32 = [](uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; };
+	bool ok = true;
+	auto chunk = [&](const char* type, const uint8_t* data, uint32_t n) {
+		uint8_t hdr[8];
+		be32(hdr, n); memcpy(hdr + 4, type, 4);
+		uint32_t crc = (uint32_t)crc32(0L, hdr + 4, 4);
+		if (n) crc = (uint32_t)crc32(crc, data, n);
+		uint8_t tail[4];
+		be32(tail, crc);
+		ok = ok && fwrite(hdr, 1, 8, f) == 8 && (n == 0 || fwrite(data, 1, n, f) == n) && fwrite(tail, 1, 4, f) == 4;
+	};
+	static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+	ok = fwrite(sig, 1, 8, f) == 8;
+	uint8_t ihdr[13];
+	be32(ihdr, width); be32(ihdr + 4, height);
+	ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0; // 8-bit RGBA, deflate, adaptive filtering, no interlace
+	chunk("IHDR", ihdr, 13);
+	chunk("IDAT", z.data(), (uint32_t)zn);
+	chunk("IEND", nullptr, 0);
+	ok = (fclose(f) == 0) && ok;
+	if (!ok) return vkr_set_error_ext(VKR_E_IO, "%s: write failed", path);
+	return VKR_OK;
+}
+
 extern "C" int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** out)
 {
 	if (!ctx || !path || !out) return vkr_set_error_ext(VKR_E_INVALID, "vkr_scene_load: NULL argument");

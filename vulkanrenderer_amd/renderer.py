@@ -19,7 +19,7 @@ EXPORTS = [
     "vkr_scene_destroy", "vkr_scene_stats", "vkr_scene_read_texture_level", "vkr_render", "vkr_wait",
     "vkr_update_scene_uniforms", "vkr_update_depth_mvp_uniforms", "vkr_default_lights", "vkr_make_uniforms",
     "vkr_profile_enable", "vkr_profile_reset", "vkr_stage_count", "vkr_stage_name", "vkr_profile_get",
-    "vkr_context_stream", "vkr_decode_png_file", "vkr_free",
+    "vkr_context_stream", "vkr_decode_png_file", "vkr_free", "vkr_write_png_file",
 ]
 
 
@@ -60,6 +60,7 @@ def lib():
         L.vkr_stage_name.argtypes = [C.c_int]
         L.vkr_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.vkr_decode_png_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.vkr_write_png_file.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
         L.vkr_free.argtypes = [C.c_void_p]
         L.vkr_free.restype = None
         L.vkr_context_stream.restype = C.c_void_p
@@ -88,6 +89,12 @@ def decode_png(path):
         return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy()
     finally:
         lib().vkr_free(p)
+
+
+def write_png(path, rgba8, flip=False):
+    """rgba8: uint8[h, w, 4]; row 0 = top unless flip."""
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    _check(lib().vkr_write_png_file(path.encode(), a.ctypes.data, a.shape[1], a.shape[0], int(flip)))
 
 
 SIDE = ("rgba8", "tri_id", "depth_bits", "mip_level", "stencil", "gbuf_normal", "gbuf_albedo", "shadow_map")
