@@ -218,6 +218,30 @@ VKR_API void vkr_default_lights(vkr_light_uniform* forwardLight, vkr_multiple_li
 VKR_API void vkr_make_uniforms(vkr_uniforms* u, uint32_t width, uint32_t height,
                        const float camera2world[16], int32_t debugVisualisation);
 
+/* The camera part of the reference's UserState (main/main.cpp:111-125) and
+ * its input slots in EInputState order (main/main.cpp:98-109), for hosts that
+ * replay a recorded input trace as a stream of poses instead of keeping glm. */
+enum {
+	VKR_INPUT_FORWARD = 0, VKR_INPUT_BACKWARD, VKR_INPUT_STRAFE_LEFT, VKR_INPUT_STRAFE_RIGHT,
+	VKR_INPUT_LEVITATE, VKR_INPUT_SINK, VKR_INPUT_FAST, VKR_INPUT_SLOW, VKR_INPUT_MOUSING,
+	VKR_INPUT_COUNT
+};
+typedef struct vkr_user_state {
+	uint8_t inputMap[VKR_INPUT_COUNT]; /* non-zero = held */
+	uint8_t wasMousing;
+	uint8_t _pad[2];
+	float mouseX, mouseY;
+	float previousX, previousY;
+	float camera2world[16];            /* column-major, identity at start */
+} vkr_user_state;
+/* Zeroes the inputs and sets camera2world to identity (main/main.cpp:124). */
+VKR_API void vkr_user_state_init(vkr_user_state* state);
+/* One step of update_user_state (main/main.cpp:3643-3679): mouse look while
+ * `mousing` is held on two consecutive steps (0.01 rad per pixel, pitch then
+ * yaw, post-multiplied), then translation by elapsedSeconds * 1.7 (x7 fast,
+ * x0.05 slow) along the camera's own axes, in the reference's key order. */
+VKR_API void vkr_update_user_state(vkr_user_state* state, float elapsedSeconds);
+
 /* ---- measurement ---- */
 
 /* Stage timing with HIP events on the context's stream.  Stage names are

@@ -40,6 +40,8 @@ def lib():
         L.ora_update_scene_uniforms.argtypes = [C.POINTER(abi.SceneUniform), C.c_uint32, C.c_uint32,
                                                 C.POINTER(C.c_float)]
         L.ora_update_depth_mvp_uniforms.argtypes = [C.POINTER(abi.DepthMVP), C.POINTER(C.c_float)]
+        L.ora_update_user_state.argtypes = [C.POINTER(abi.UserState), C.c_float]
+        L.ora_update_user_state.restype = None
         L.ora_default_lights.argtypes = [C.POINTER(abi.LightUniform), C.POINTER(abi.MultipleLights)]
         L.ora_decode_tbn.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
         L.ora_pack_tbn.restype = C.c_uint32

@@ -11,6 +11,7 @@
 //        ref_fixtures tangents            -> JSON on stdout
 //        ref_fixtures loadmodel <file>    -> JSON on stdout
 //        ref_fixtures stb <png>...        -> JSON on stdout (stbi_load(...,4) flipped, as utils/vkimage.cpp:62-65)
+//        ref_fixtures userstate           -> JSON on stdout (camera2world after each step of an input trace)
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -190,13 +191,78 @@ static int do_stb(int n, char** files)
 	return 0;
 }
 
+// The input trace the user-state fixture is made of: per step the held keys
+// (bit i = EInputState i), the cursor position and the frame time.
+struct TraceStep { unsigned keys; float mouseX, mouseY, dt; };
+static const TraceStep kTrace[] = {
+	{ 0x001, 0.f, 0.f, 0.016f },               // forward
+	{ 0x041, 0.f, 0.f, 0.0166667f },           // forward, fast
+	{ 0x100, 400.f, 300.f, 0.0166667f },       // mousing starts: no rotation yet
+	{ 0x100, 437.f, 282.f, 0.0166667f },       // look
+	{ 0x108, 431.5f, 310.25f, 0.02f },         // look + strafe right
+	{ 0x000, 900.f, 10.f, 0.01f },             // released: cursor moves freely
+	{ 0x100, 120.f, 620.f, 0.01f },            // mousing again: first step only latches
+	{ 0x185, 119.f, 640.f, 0.033f },           // look + forward + strafe left + slow
+	{ 0x0c2, 0.f, 0.f, 0.25f },                // backward, fast and slow together
+	{ 0x030, 0.f, 0.f, 0.0166667f },           // levitate and sink cancel (up to rounding)
+	{ 0x010, 0.f, 0.f, 1.5f },                 // levitate, long frame
+	{ 0x120, -250.f, 75.f, 0.0166667f },       // sink + mousing latch
+	{ 0x13f, 1650.f, -830.f, 0.0166667f },     // every movement key, big mouse delta
+	{ 0x101, 1650.f, -830.f, 0.0f },           // zero frame time, zero mouse delta
+};
+
+static int do_userstate()
+{
+	// The statements of update_user_state (main/main.cpp:3643-3679) on glm's own
+	// types, with the constants of main/main.cpp:76-84.
+	constexpr float kCameraBaseSpeed = 1.7f, kCameraFastMult = 7.0f, kCameraSlowMult = 0.05f, kCameraMouseSensitivity = 0.01f;
+	glm::mat4 cam = glm::identity<glm::mat4>();
+	float previousX = 0.f, previousY = 0.f;
+	bool wasMousing = false;
+	std::printf("{\n  \"steps\": [\n");
+	const std::size_t n = sizeof(kTrace) / sizeof(kTrace[0]);
+	for (std::size_t i = 0; i < n; i++) {
+		TraceStep const& t = kTrace[i];
+		auto held = [&](int k) { return ((t.keys >> k) & 1u) != 0; };
+		if (held(8)) {
+			if (wasMousing) {
+				const auto sens = kCameraMouseSensitivity;
+				const auto dx = sens * (t.mouseX - previousX);
+				const auto dy = sens * (t.mouseY - previousY);
+				cam = cam * glm::rotate(-dy, glm::vec3(1.0f, 0.0f, 0.0f));
+				cam = cam * glm::rotate(-dx, glm::vec3(0.0f, 1.0f, 0.0f));
+			}
+			previousX = t.mouseX;
+			previousY = t.mouseY;
+			wasMousing = true;
+		} else {
+			wasMousing = false;
+		}
+		const auto move = t.dt * kCameraBaseSpeed * (held(6) ? kCameraFastMult : 1.0f) * (held(7) ? kCameraSlowMult : 1.0f);
+		if (held(0)) cam = cam * glm::translate(glm::vec3(0.f, 0.f, -move));
+		if (held(1)) cam = cam * glm::translate(glm::vec3(0.f, 0.f, +move));
+		if (held(2)) cam = cam * glm::translate(glm::vec3(-move, 0.f, 0.f));
+		if (held(3)) cam = cam * glm::translate(glm::vec3(+move, 0.f, 0.f));
+		if (held(4)) cam = cam * glm::translate(glm::vec3(0.f, +move, 0.f));
+		if (held(5)) cam = cam * glm::translate(glm::vec3(0.f, -move, 0.f));
+		std::uint32_t mx, my, dt;
+		std::memcpy(&mx, &t.mouseX, 4); std::memcpy(&my, &t.mouseY, 4); std::memcpy(&dt, &t.dt, 4);
+		std::printf("  {\n    \"keys\": %u, \"mouseX\": %u, \"mouseY\": %u, \"dt\": %u, \"wasMousing\": %d,\n", t.keys, mx, my, dt, wasMousing ? 1 : 0);
+		print_mat("camera2world", cam, true);
+		std::printf("  }%s\n", i + 1 < n ? "," : "");
+	}
+	std::printf("  ]\n}\n");
+	return 0;
+}
+
 int main(int argc, char** argv)
 try {
 	if (argc >= 2 && 0 == std::strcmp(argv[1], "matrices")) return do_matrices();
 	if (argc >= 2 && 0 == std::strcmp(argv[1], "tangents")) return do_tangents();
+	if (argc >= 2 && 0 == std::strcmp(argv[1], "userstate")) return do_userstate();
 	if (argc >= 3 && 0 == std::strcmp(argv[1], "loadmodel")) return do_loadmodel(argv[2]);
 	if (argc >= 3 && 0 == std::strcmp(argv[1], "stb")) return do_stb(argc - 2, argv + 2);
-	std::fprintf(stderr, "usage: ref_fixtures matrices|tangents|loadmodel <file>\n");
+	std::fprintf(stderr, "usage: ref_fixtures matrices|tangents|userstate|loadmodel <file>|stb <png>...\n");
 	return 2;
 } catch (std::exception const& e) {
 	std::fprintf(stderr, "error: %s\n", e.what());

@@ -564,6 +564,94 @@ ORA_API void ora_make_uniforms(vkr_uniforms* u, uint32_t w, uint32_t h, const fl
 	ora_update_depth_mvp_uniforms(&u->depthMVPUniform, u->lightUniforms.lightPos);
 }
 
+/* Column c of an identity matrix scaled by k, accumulated the way glm's
+ * vec4 operators do it: m[0]*k0 + m[1]*k1 + m[2]*k2 (+ m[3]). */
+static void glm_identity_combo(const float k[3], int addLast, float out[4])
+{
+	for (int r = 0; r < 4; r++) {
+		float e0 = (r == 0) ? 1.0f : 0.0f, e1 = (r == 1) ? 1.0f : 0.0f, e2 = (r == 2) ? 1.0f : 0.0f, e3 = (r == 3) ? 1.0f : 0.0f;
+		float p0 = e0 * k[0], p1 = e1 * k[1], p2 = e2 * k[2];
+		float acc = p0 + p1;
+		acc = acc + p2;
+		if (addLast) acc = acc + e3;
+		out[r] = acc;
+	}
+}
+
+/* glm::rotate(angle, v) = rotate(mat4(1), angle, v)
+ * (third_party/glm/include/glm/gtx/transform.inl:12-15,
+ *  third_party/glm/include/glm/ext/matrix_transform.inl:18-46) */
+static void glm_rotate(float angle, const float v[3], float out[16])
+{
+	float c = cosf(angle), s = sinf(angle);
+	float axis[3], temp[3], rc[3];
+	glm_normalize3(v, axis);
+	float omc = 1.0f - c;
+	for (int i = 0; i < 3; i++) temp[i] = omc * axis[i];
+	rc[0] = c + temp[0] * axis[0];
+	rc[1] = temp[0] * axis[1] + s * axis[2];
+	rc[2] = temp[0] * axis[2] - s * axis[1];
+	glm_identity_combo(rc, 0, out + 0);
+	rc[0] = temp[1] * axis[0] - s * axis[2];
+	rc[1] = c + temp[1] * axis[1];
+	rc[2] = temp[1] * axis[2] + s * axis[0];
+	glm_identity_combo(rc, 0, out + 4);
+	rc[0] = temp[2] * axis[0] + s * axis[1];
+	rc[1] = temp[2] * axis[1] - s * axis[0];
+	rc[2] = c + temp[2] * axis[2];
+	glm_identity_combo(rc, 0, out + 8);
+	out[12] = 0.0f; out[13] = 0.0f; out[14] = 0.0f; out[15] = 1.0f;
+}
+
+/* glm::translate(v) = translate(mat4(1), v)
+ * (gtx/transform.inl:6-9, ext/matrix_transform.inl:10-15) */
+static void glm_translate(float x, float y, float z, float out[16])
+{
+	float v[3] = { x, y, z };
+	memset(out, 0, sizeof(float) * 16);
+	out[0] = out[5] = out[10] = 1.0f;
+	glm_identity_combo(v, 1, out + 12);
+}
+
+/* update_user_state, main/main.cpp:3643-3679; constants main/main.cpp:76-84 */
+ORA_API void ora_update_user_state(vkr_user_state* st, float elapsed)
+{
+	float t[16];
+	if (st->inputMap[VKR_INPUT_MOUSING]) {
+		if (st->wasMousing) {
+			float sens = 0.01f;
+			float dx = sens * (st->mouseX - st->previousX);
+			float dy = sens * (st->mouseY - st->previousY);
+			float ax[3] = { 1.0f, 0.0f, 0.0f }, ay[3] = { 0.0f, 1.0f, 0.0f };
+			glm_rotate(-dy, ax, t);
+			mat4_mul(st->camera2world, t, st->camera2world);
+			glm_rotate(-dx, ay, t);
+			mat4_mul(st->camera2world, t, st->camera2world);
+		}
+		st->previousX = st->mouseX;
+		st->previousY = st->mouseY;
+		st->wasMousing = 1;
+	} else {
+		st->wasMousing = 0;
+	}
+	float move = elapsed * 1.7f;
+	move = move * (st->inputMap[VKR_INPUT_FAST] ? 7.0f : 1.0f);
+	move = move * (st->inputMap[VKR_INPUT_SLOW] ? 0.05f : 1.0f);
+	static const struct { int key; float x, y, z; } dirs[6] = {
+		{ VKR_INPUT_FORWARD, 0.f, 0.f, -1.f }, { VKR_INPUT_BACKWARD, 0.f, 0.f, 1.f },
+		{ VKR_INPUT_STRAFE_LEFT, -1.f, 0.f, 0.f }, { VKR_INPUT_STRAFE_RIGHT, 1.f, 0.f, 0.f },
+		{ VKR_INPUT_LEVITATE, 0.f, 1.f, 0.f }, { VKR_INPUT_SINK, 0.f, -1.f, 0.f } };
+	for (int i = 0; i < 6; i++)
+		if (st->inputMap[dirs[i].key]) {
+			/* the reference passes +-move and literal 0.f components */
+			float x = dirs[i].x == 0.f ? 0.f : (dirs[i].x < 0.f ? -move : move);
+			float y = dirs[i].y == 0.f ? 0.f : (dirs[i].y < 0.f ? -move : move);
+			float z = dirs[i].z == 0.f ? 0.f : (dirs[i].z < 0.f ? -move : move);
+			glm_translate(x, y, z, t);
+			mat4_mul(st->camera2world, t, st->camera2world);
+		}
+}
+
 /* ------------------------------------------------------------------------ */
 /* TBN quaternion packing                                                    */
 /* ------------------------------------------------------------------------ */

@@ -106,6 +106,44 @@ def test_make_uniforms_oracle_equals_product():
             assert bytes(oracle.make_uniforms(w, h, pose, 3)) == bytes(renderer.make_uniforms(w, h, pose, 3))
 
 
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_user_state_trace_bit_exact(impl):
+    """update_user_state (main/main.cpp:3643-3679) over a 14-step input trace:
+    mouse latch, pitch/yaw order, fast/slow multipliers, key order, zero frame time."""
+    from oracle import oracle
+    from vulkanrenderer_amd import abi, renderer
+    ref = json.load(open(os.path.join(GOLD, "ref_userstate.json")))["steps"]
+    assert len(ref) == 14
+    step = oracle.lib().ora_update_user_state if impl == "oracle" else renderer.lib().vkr_update_user_state
+    st = abi.UserState()
+    renderer.lib().vkr_user_state_init(C.byref(st))
+    assert list(st.camera2world) == [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+    for i, e in enumerate(ref):
+        for k in range(9):
+            st.inputMap[k] = (e["keys"] >> k) & 1
+        st.mouseX, st.mouseY = float(f32([e["mouseX"]])[0]), float(f32([e["mouseY"]])[0])
+        step(C.byref(st), float(f32([e["dt"]])[0]))
+        assert np.array_equal(bits(st.camera2world), np.array(e["camera2world"], np.uint32)), (impl, i)
+        assert st.wasMousing == e["wasMousing"]
+    # the trace rotates and moves: the final pose is a rigid transform away from identity
+    m = np.array(st.camera2world, np.float32).reshape(4, 4).T
+    assert abs(np.linalg.det(m[:3, :3]) - 1) < 1e-5 and np.abs(m[:3, 3]).max() > 1
+
+
+def test_replay_inputs_yields_renderable_poses():
+    from vulkanrenderer_amd import renderer
+    trace = [({"forward"}, 0, 0, 0.5), ({"mousing"}, 10, 10, 0.016), ({"mousing", "strafeLeft", "fast"}, 60, 4, 0.016)]
+    poses, st = renderer.replay_inputs(trace)
+    assert poses.shape == (3, 16) and poses.dtype == np.float32
+    assert poses[0].tolist() == [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, np.float32(-0.5) * np.float32(1.7), 1]
+    assert np.array_equal(poses[1], poses[0]) and st.wasMousing == 1  # first mousing step only latches the cursor
+    assert not np.array_equal(poses[2][:12], poses[1][:12])
+    u = renderer.make_uniforms(64, 36, poses[2])
+    assert np.isfinite(np.array(u.sceneUniforms.projCam)).all()
+    more, _ = renderer.replay_inputs([(1 << 1, 0, 0, 0.5)], st)   # bit mask form, continues from the state
+    assert more.shape == (1, 16)
+
+
 def test_tbn_packer_matches_make_indexed_mesh():
     """main-bake/index_mesh.cpp:178-220 run on a 30-vertex mesh through tgen."""
     from oracle import oracle

@@ -283,6 +283,77 @@ extern "C" void vkr_make_uniforms(vkr_uniforms* u, uint32_t width, uint32_t heig
 	vkr_update_depth_mvp_uniforms(&u->depthMVPUniform, u->lightUniforms.lightPos);
 }
 
+// cam = cam * glm::rotate(angle, axis) for a unit axis (gtx/transform.inl:12-15 over
+// ext/matrix_transform.inl:18-46): the rotation is first applied to an identity
+// matrix, zeros and ones included, so that signed zeros come out as glm's do.
+static void post_rotate(float cam[16], float angle, const float axis[3])
+{
+	const float c = cosf(angle), s = sinf(angle);
+	const float temp[3] = { (1.0f - c) * axis[0], (1.0f - c) * axis[1], (1.0f - c) * axis[2] };
+	float R[3][3];
+	R[0][0] = c + temp[0] * axis[0];
+	R[0][1] = temp[0] * axis[1] + s * axis[2];
+	R[0][2] = temp[0] * axis[2] - s * axis[1];
+	R[1][0] = temp[1] * axis[0] - s * axis[2];
+	R[1][1] = c + temp[1] * axis[1];
+	R[1][2] = temp[1] * axis[2] + s * axis[0];
+	R[2][0] = temp[2] * axis[0] + s * axis[1];
+	R[2][1] = temp[2] * axis[1] - s * axis[0];
+	R[2][2] = c + temp[2] * axis[2];
+	static const float I[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+	float rot[16];
+	for (int col = 0; col < 3; col++)
+		for (int i = 0; i < 4; i++)
+			rot[col * 4 + i] = (I[0 + i] * R[col][0] + I[4 + i] * R[col][1]) + I[8 + i] * R[col][2];
+	for (int i = 0; i < 4; i++) rot[12 + i] = I[12 + i];
+	mat4_mul(cam, rot, cam);
+}
+
+// cam = cam * glm::translate(v) (gtx/transform.inl:6-9 over ext/matrix_transform.inl:10-15)
+static void post_translate(float cam[16], float x, float y, float z)
+{
+	static const float I[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+	float tr[16];
+	memcpy(tr, I, sizeof tr);
+	for (int i = 0; i < 4; i++) tr[12 + i] = ((I[0 + i] * x + I[4 + i] * y) + I[8 + i] * z) + I[12 + i];
+	mat4_mul(cam, tr, cam);
+}
+
+extern "C" void vkr_user_state_init(vkr_user_state* st)
+{
+	memset(st, 0, sizeof *st);
+	st->camera2world[0] = st->camera2world[5] = st->camera2world[10] = st->camera2world[15] = 1.0f;
+}
+
+extern "C" void vkr_update_user_state(vkr_user_state* st, float elapsed)
+{
+	// main/main.cpp:3643-3679 with the constants of main/main.cpp:76-84
+	const float kBaseSpeed = 1.7f, kFastMult = 7.0f, kSlowMult = 0.05f, kMouseSensitivity = 0.01f;
+	float* cam = st->camera2world;
+	if (st->inputMap[VKR_INPUT_MOUSING]) {
+		if (st->wasMousing) {
+			const float dx = kMouseSensitivity * (st->mouseX - st->previousX);
+			const float dy = kMouseSensitivity * (st->mouseY - st->previousY);
+			const float xAxis[3] = { 1.0f, 0.0f, 0.0f }, yAxis[3] = { 0.0f, 1.0f, 0.0f };
+			post_rotate(cam, -dy, xAxis);
+			post_rotate(cam, -dx, yAxis);
+		}
+		st->previousX = st->mouseX;
+		st->previousY = st->mouseY;
+		st->wasMousing = 1;
+	} else
+		st->wasMousing = 0;
+
+	const float move = elapsed * kBaseSpeed * (st->inputMap[VKR_INPUT_FAST] ? kFastMult : 1.0f) *
+	                   (st->inputMap[VKR_INPUT_SLOW] ? kSlowMult : 1.0f);
+	if (st->inputMap[VKR_INPUT_FORWARD]) post_translate(cam, 0.0f, 0.0f, -move);
+	if (st->inputMap[VKR_INPUT_BACKWARD]) post_translate(cam, 0.0f, 0.0f, +move);
+	if (st->inputMap[VKR_INPUT_STRAFE_LEFT]) post_translate(cam, -move, 0.0f, 0.0f);
+	if (st->inputMap[VKR_INPUT_STRAFE_RIGHT]) post_translate(cam, +move, 0.0f, 0.0f);
+	if (st->inputMap[VKR_INPUT_LEVITATE]) post_translate(cam, 0.0f, +move, 0.0f);
+	if (st->inputMap[VKR_INPUT_SINK]) post_translate(cam, 0.0f, -move, 0.0f);
+}
+
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------

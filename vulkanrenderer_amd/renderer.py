@@ -20,6 +20,7 @@ EXPORTS = [
     "vkr_update_scene_uniforms", "vkr_update_depth_mvp_uniforms", "vkr_default_lights", "vkr_make_uniforms",
     "vkr_profile_enable", "vkr_profile_reset", "vkr_stage_count", "vkr_stage_name", "vkr_profile_get",
     "vkr_context_stream", "vkr_decode_png_file", "vkr_free", "vkr_write_png_file",
+    "vkr_user_state_init", "vkr_update_user_state",
 ]
 
 
@@ -61,6 +62,10 @@ def lib():
         L.vkr_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.vkr_decode_png_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.vkr_write_png_file.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
+        L.vkr_user_state_init.argtypes = [C.POINTER(abi.UserState)]
+        L.vkr_user_state_init.restype = None
+        L.vkr_update_user_state.argtypes = [C.POINTER(abi.UserState), C.c_float]
+        L.vkr_update_user_state.restype = None
         L.vkr_free.argtypes = [C.c_void_p]
         L.vkr_free.restype = None
         L.vkr_context_stream.restype = C.c_void_p
@@ -79,6 +84,29 @@ def make_uniforms(width, height, camera2world_c16, debug=1):
     u = abi.Uniforms()
     lib().vkr_make_uniforms(C.byref(u), width, height, (C.c_float * 16)(*[float(v) for v in camera2world_c16]), debug)
     return u
+
+
+def replay_inputs(trace, state=None):
+    """Turns a recorded input trace into the stream of camera poses the
+    reference's frame loop would have rendered (update_user_state,
+    main/main.cpp:3643-3679, called once per frame at main/main.cpp:1302).
+    trace: iterable of (held_keys, mouseX, mouseY, dt) with held_keys a set of
+    names from abi.INPUT_KEYS or a bit mask in that order.  Returns float32[n, 16]
+    column-major camera2world matrices (one per step) and the final state."""
+    L = lib()
+    if state is None:
+        state = abi.UserState()
+        L.vkr_user_state_init(C.byref(state))
+    poses = []
+    for keys, mx, my, dt in trace:
+        if not isinstance(keys, int):
+            keys = sum(1 << abi.INPUT_KEYS.index(k) for k in keys)
+        for i in range(9):
+            state.inputMap[i] = (keys >> i) & 1
+        state.mouseX, state.mouseY = mx, my
+        L.vkr_update_user_state(C.byref(state), dt)
+        poses.append(np.array(state.camera2world, np.float32))
+    return np.array(poses, np.float32).reshape(-1, 16), state
 
 
 def decode_png(path):
