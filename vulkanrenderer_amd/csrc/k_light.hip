@@ -15,7 +15,7 @@
 //    N.H = (N.V+N.L)/|V+L|,  V.H = (1+V.L)/|V+L| = 1/(2 invh) with
 //    invh = rsq(2(1+V.L)); H itself is never formed and 1/(V.H) = 2 invh.
 //  * D's exponent (nh^2-1)/(r^2 nh^2) = (1 - 1/nh^2)/r^2: one rcp, one fma.
-//  * D's denominator and the BRDF denominator share one reciprocal.
+//  * D's denominator, the BRDF denominator and the 1/nh^2 of D's exponent share one reciprocal.
 //  * The Fresnel/diffuse/specular mix is linear in three per-light scalars:
 //      brdf_c = kd_c (1-f0_c) (1-x^5) + f0_c spec + (1-f0_c) spec x^5,  x = 1 - V.H,
 //    so when every light has the same colour (the reference's 21 braziers,
@@ -23,7 +23,7 @@
 //    the loop accumulates S1 = sum t(1-x^5), S2 = sum t spec, S3 = sum t spec x^5
 //    (t = N.L/d^2) and the channels are combined once at the end.
 //  * max(.,0) of quantities bounded by 1 uses the free clamp modifier.
-// Per light: 42 plain VALU instructions and 5 transcendentals (2 rsq, 2 rcp, 1 exp2).  Measured on
+// Per light: 43 plain VALU instructions and 4 transcendentals (2 rsq, 1 rcp, 1 exp2).  Measured on
 // MI355X (tools/microbench/light_loop.hip, trans_mix.hip): a plain f32 instruction costs ~2.4 SIMD
 // cycles per wavefront, a transcendental ~8 in a pure stream but 13-16 when mixed with plain ones, so
 // the five transcendentals are ~40 % of the loop; the kernel keeps the vector ALU busy ~100 % of the time.
@@ -43,22 +43,24 @@ __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 	vkr_load_srgb_table(sT, a.srgbThresh);
 	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
-	const uint32_t n = rw * rh;
-	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-	if (p >= n) return;
+	// a workgroup shades 16x16 pixels, each wavefront an 8x8 block: the pixels of a wavefront mostly lie on
+	// one surface, which is what lets whole wavefronts skip the lights behind it (below)
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	const uint32_t x = blockIdx.x * 16u + (wv & 1u) * 8u + (lane & 7u), y = blockIdx.y * 16u + (wv >> 1) * 8u + (lane >> 3);
+	if (x >= rw || y >= rh) return;
+	const uint32_t p = y * rw + x;
 	const float depth = a.depth[p];
 	if (depth == 1.0f) { a.colour[p] = a.clearColour; return; } // discard: the clear colour stays
 	const uint2 gn = a.gN[p], ga = a.gA[p];
-	const uint32_t x = p % rw, y = p / rw;
 	const float px = (float)(a.view.x0 + x), py = (float)(a.view.y0 + y);
 	// posFromDepth: clip = (uv*2-1, depth, 1); world = (inverse(camera)*inverse(projection)) * clip
-	const float cx = ((px + 0.5f) / (float)a.view.W) * 2.0f - 1.0f;
-	const float cy = ((py + 0.5f) / (float)a.view.H) * 2.0f - 1.0f;
+	const float cx = ((px + 0.5f) * fast_rcp((float)a.view.W)) * 2.0f - 1.0f;
+	const float cy = ((py + 0.5f) * fast_rcp((float)a.view.H)) * 2.0f - 1.0f;
 	float vs[4];
 #pragma unroll
 	for (int i = 0; i < 4; i++)
 		vs[i] = a.invPC.m[0 * 4 + i] * cx + a.invPC.m[1 * 4 + i] * cy + a.invPC.m[2 * 4 + i] * depth + a.invPC.m[3 * 4 + i];
-	const float iw = 1.0f / vs[3];
+	const float iw = fast_rcp(vs[3]);
 	const float Px = vs[0] * iw, Py = vs[1] * iw, Pz = vs[2] * iw;
 	float Vx = a.camPos[0] - Px, Vy = a.camPos[1] - Py, Vz = a.camPos[2] - Pz;
 	{
@@ -80,8 +82,8 @@ __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 	// light-independent terms
 	const float ndv = Nx * Vx + Ny * Vy + Nz * Vz;
 	const float ndvp = fmaxf(ndv, 0.0f);
-	const float pir2 = PI * r2;
-	const float cexp = LOG2E / fmaxf(r2, 1.0e-30f); // exponent of D is cexp * (1 - 1/nh^2)
+	const float pir2x4 = 4.0f * PI * r2;
+	const float cexp = LOG2E * fast_rcp(fmaxf(r2, 1.0e-30f)); // exponent of D is cexp * (1 - 1/nh^2)
 	const float V2x = Vx + Vx, V2y = Vy + Vy, V2z = Vz + Vz;
 	const float om = 1.0f - metal;
 	float f0[3], omf0[3], kdo[3];
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 	for (int c = 0; c < 3; c++) {
 		f0[c] = om * 0.04f + metal * alb[c];
 		omf0[c] = 1.0f - f0[c];
-		kdo[c] = (alb[c] / PI) * om * omf0[c];
+		kdo[c] = (alb[c] * (1.0f / PI)) * om * omf0[c];
 	}
 	float S0 = 0.0f;                          // sum 1/d^2 (ambient)
 	float S1[3] = { 0, 0, 0 }, S2[3] = { 0, 0, 0 }, S3[3] = { 0, 0, 0 }; // SAMECOL: only [0] is used
@@ -100,25 +102,29 @@ __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 		const float invd = fast_rsq(d2);
 		const float invd2 = invd * invd;
 		const float nl = Nx * Lx + Ny * Ly + Nz * Lz;
+		S0 += invd2;
+		// every term below carries the factor max(N.L, 0): a light behind every surface of the wavefront adds nothing
+		if (__builtin_amdgcn_ballot_w64(nl > 0.0f) == 0) continue;
 		const float ndl = nl * invd;
 		const float ndlp = sat(nl * invd);                       // max(N.L, 0); N.L <= 1
 		const float opv2 = (V2x * Lx + V2y * Ly + V2z * Lz) * invd + 2.0f; // 2 (1 + V.L) = |V+L|^2
 		const float invh = fast_rsq(opv2);
 		const float xx = 1.0f - 0.5f * (opv2 * invh);           // 1 - V.H
 		const float ndh = sat((ndv + ndl) * invh);               // max(N.H, 0)
-		const float nh2 = ndh * ndh, nh4 = nh2 * nh2;
-		const float ex = fast_exp2(cexp - cexp * fast_rcp(nh2));
-		// D's denominator times a quarter of the BRDF denominator, one reciprocal for both
-		const float rden = fast_rcp((0.001f + pir2 * nh4) * (0.00025f + ndvp * ndlp));
+		const float nh2 = fmaf(ndh, ndh, 1.0e-30f), nh4 = nh2 * nh2; // the offset keeps the shared reciprocal finite
+		// D's denominator times the BRDF denominator, and 1/nh^2 for D's exponent, from one reciprocal
+		const float den = (0.004f + pir2x4 * nh4) * (0.00025f + ndvp * ndlp);
+		const float rr = fast_rcp(den * nh2);
+		const float ex = fast_exp2(cexp - cexp * (rr * den));
+		const float rden = rr * nh2;                             // 1 / (4 (0.001 + pi r^2 nh^4) (0.00025 + n.v n.l))
 		const float x2 = xx * xx, x5 = x2 * x2 * xx;
-		// G/4 = min(1/4, n.h min(n.v, n.l) / (2 v.h)),  1/(2 v.h) = invh
-		const float Gq = fminf((ndh * invh) * fminf(ndvp, ndlp), 0.25f);
-		const float spec = ex * Gq * rden;                       // D G / (0.001 + 4 n.v n.l)
+		// G = min(1, 2 n.h min(n.v, n.l) / v.h) with 1/(2 v.h) = invh
+		const float G = sat(4.0f * ((ndh * invh) * fminf(ndvp, ndlp)));
+		const float spec = ex * G * rden;                        // D G / (0.001 + 4 n.v n.l)
 		const float t = ndlp * invd2;
 		const float ts = t * spec;
 		const float ty = t - t * x5;                             // t (1 - x^5)
 		const float tsx = ts * x5;
-		S0 += invd2;
 		if (SAMECOL) {
 			S1[0] += ty; S2[0] += ts; S3[0] += tsx;
 		} else {
@@ -225,8 +231,9 @@ void vkr_launch_deferred_light(hipStream_t s, const LightArgs& a)
 	bool same = true;
 	for (int i = 1; i < VKR_NUM_LIGHTS_K; i++)
 		for (int c = 0; c < 3; c++) same = same && a.lightCol[i][c] == a.lightCol[0][c];
-	if (same) hipLaunchKernelGGL((k_deferred_light<true>), dim3((n + 255) / 256), dim3(256), 0, s, a);
-	else hipLaunchKernelGGL((k_deferred_light<false>), dim3((n + 255) / 256), dim3(256), 0, s, a);
+	const dim3 grid((a.view.x1 - a.view.x0 + 15) / 16, (a.view.y1 - a.view.y0 + 15) / 16);
+	if (same) hipLaunchKernelGGL((k_deferred_light<true>), grid, dim3(256), 0, s, a);
+	else hipLaunchKernelGGL((k_deferred_light<false>), grid, dim3(256), 0, s, a);
 }
 
 void vkr_launch_overvis_colour(hipStream_t s, const uint8_t* stencil, uint32_t* colour, const float* srgbThresh, uint32_t n)
