@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 						t.t1 = make_float2(a.sc.uv[2 * (size_t)i1], a.sc.uv[2 * (size_t)i1 + 1]);
 						t.t2 = make_float2(a.sc.uv[2 * (size_t)i2], a.sc.uv[2 * (size_t)i2 + 1]);
 						const TexInfo& tex = a.sc.tex[a.sc.mat[a.sc.triMat[s.prim]].tex[3]];
-						t.off0 = tex.alphaOff; t.w0 = tex.w[0]; t.h0 = tex.h[0]; t.levels = tex.levels;
+						t.off0 = tex.alphaOff; t.w0 = tex.wh0 & 0xffffu; t.h0 = tex.wh0 >> 16; t.levels = tex.levels;
 					}
 				}
 			}

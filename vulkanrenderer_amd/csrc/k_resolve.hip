@@ -73,7 +73,7 @@ __device__ __forceinline__ void shading_normal(const ResolveArgs& a, const Frag&
 // The four material fetches of gBufWrite.frag / default.frag: normal map rgb,
 // base colour rgb, metalness r, roughness r.  The footprint (level, weights,
 // texel indices) is rebuilt only when a texture's size differs from the
-// previous one's.
+// previous one's; materials with repacked chains take two fetches.
 struct MatSample { float nm[4], alb[4], metal, rough; };
 
 __device__ __forceinline__ void sample_material(const ResolveArgs& a, const Frag& f, const float* dec, MatSample& o)
@@ -81,6 +81,16 @@ __device__ __forceinline__ void sample_material(const ResolveArgs& a, const Frag
 	const MatInfo& mi = a.sc.mat[f.mat];
 	TexTaps tp;
 	float t[4];
+	if (mi.packNM != 0xffffffffu) {
+		// the four textures have one size: (normal.rgb, metalness.r) and (baseColor.rgb, roughness.r) per texel
+		const TexInfo& tn = a.sc.tex[mi.packNM];
+		vkr_make_taps(tn, f.uv[0], f.uv[1], f.d, tp);
+		vkr_fetch<15>(a.sc, tn, tp, dec, o.nm);
+		o.metal = o.nm[3];
+		vkr_fetch<15>(a.sc, a.sc.tex[mi.packAR], tp, dec, o.alb);
+		o.rough = o.alb[3];
+		return;
+	}
 	const TexInfo& tn = a.sc.tex[mi.tex[4]];
 	vkr_make_taps(tn, f.uv[0], f.uv[1], f.d, tp);
 	vkr_fetch<7>(a.sc, tn, tp, dec, o.nm);

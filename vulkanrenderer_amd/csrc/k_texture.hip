@@ -95,3 +95,20 @@ void vkr_launch_extract_alpha(hipStream_t s, const uint32_t* texels, uint8_t* ou
 	if (!n) return;
 	hipLaunchKernelGGL(k_extract_alpha, dim3((n + 255) / 256), dim3(256), 0, s, texels, out, n);
 }
+
+// ---------------------------------------------------------------------------
+// Repacked chain: the colour bytes of one chain and the first byte of another
+// (same size, levels stored back to back) in one texel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_chain(const uint32_t* __restrict__ rgb, const uint32_t* __restrict__ a,
+                                                     uint32_t* __restrict__ out, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = (rgb[i] & 0x00ffffffu) | (a[i] << 24);
+}
+
+void vkr_launch_pack_chain(hipStream_t s, const uint32_t* rgb, const uint32_t* a, uint32_t* out, uint32_t n)
+{
+	if (!n) return;
+	hipLaunchKernelGGL(k_pack_chain, dim3((n + 255) / 256), dim3(256), 0, s, rgb, a, out, n);
+}

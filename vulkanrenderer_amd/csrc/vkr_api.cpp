@@ -587,13 +587,12 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 	std::vector<TexInfo> tinfo(d->textureCount ? d->textureCount : 1);
 	s->htex.resize(d->textureCount);
 	uint64_t texels = 0;
-	for (uint32_t i = 0; i < d->textureCount; i++) {
-		const vkr_texture_desc& t = d->textures[i];
+	auto add_chain = [&](size_t i, uint32_t w, uint32_t hh, int srgb) {
 		HostTex& h = s->htex[i];
-		h.levels = mip_level_count(t.width, t.height);
-		h.srgb = t.space == 1;
-		uint32_t w = t.width, hh = t.height;
+		h.levels = mip_level_count(w, hh);
+		h.srgb = srgb;
 		memset(&tinfo[i], 0, sizeof(TexInfo));
+		tinfo[i].wh0 = w | (hh << 16);
 		for (int l = 0; l < h.levels; l++) {
 			h.w[l] = w; h.h[l] = hh; h.off[l] = (uint32_t)texels;
 			tinfo[i].offset[l] = (uint32_t)texels; tinfo[i].w[l] = (uint16_t)w; tinfo[i].h[l] = (uint16_t)hh;
@@ -602,9 +601,46 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 			hh >>= 1; if (!hh) hh = 1;
 		}
 		tinfo[i].levels = h.levels; tinfo[i].srgb = h.srgb;
+		tinfo[i].alphaOff = 0xffffffffu;
+	};
+	auto chain_texels = [&](size_t i) {
+		const HostTex& h = s->htex[i];
+		return (uint32_t)(h.off[h.levels - 1] + h.w[h.levels - 1] * h.h[h.levels - 1] - h.off[0]);
+	};
+	for (uint32_t i = 0; i < d->textureCount; i++) {
+		add_chain(i, d->textures[i].width, d->textures[i].height, d->textures[i].space == 1);
 		if (texels >= 0xffffffffull) return fail(set_error(VKR_E_LIMIT, "texel pool exceeds 2^32 texels"));
 	}
 	s->texelCount = texels;
+	// Repacked chains: a material whose normal map, base colour, metalness and roughness textures have one
+	// size gets (normal.rgb, metalness.r) and (baseColor.rgb, roughness.r) stored per texel, every level copied
+	// byte for byte from the source chains, so that shading fetches two footprints instead of four.  The fourth
+	// byte is read as a linear value, so metalness / roughness textures in an sRGB format keep the four fetches.
+	struct Pack { uint32_t rgb, a, id; };
+	std::vector<Pack> packs;
+	std::vector<std::pair<uint32_t, uint32_t>> matPack(d->materialCount, { 0xffffffffu, 0xffffffffu });
+	for (uint32_t i = 0; i < d->materialCount; i++) {
+		const vkr_material_desc& m = d->materials[i];
+		const uint32_t ids[4] = { m.normalMapTextureId, m.metalnessTextureId, m.baseColorTextureId, m.roughnessTextureId };
+		bool ok = true;
+		for (uint32_t id : ids) ok = ok && id < d->textureCount;
+		for (int k = 1; ok && k < 4; k++)
+			ok = d->textures[ids[k]].width == d->textures[ids[0]].width && d->textures[ids[k]].height == d->textures[ids[0]].height;
+		ok = ok && d->textures[ids[1]].space != 1 && d->textures[ids[3]].space != 1;
+		if (!ok) continue;
+		auto find_or_add = [&](uint32_t rgb, uint32_t a) {
+			for (const Pack& p : packs) if (p.rgb == rgb && p.a == a) return p.id;
+			const uint32_t id = (uint32_t)s->htex.size();
+			s->htex.emplace_back();
+			tinfo.emplace_back();
+			add_chain(id, d->textures[rgb].width, d->textures[rgb].height, d->textures[rgb].space == 1);
+			packs.push_back({ rgb, a, id });
+			return id;
+		};
+		matPack[i].first = find_or_add(ids[0], ids[1]);
+		matPack[i].second = find_or_add(ids[2], ids[3]);
+		if (texels >= 0xffffffffull) return fail(set_error(VKR_E_LIMIT, "texel pool exceeds 2^32 texels"));
+	}
 	if ((rc = s->texels.ensure(texels ? texels * 4 : 4))) return fail(rc);
 	for (uint32_t i = 0; i < d->textureCount; i++) {
 		const vkr_texture_desc& t = d->textures[i];
@@ -615,7 +651,9 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 			vkr_launch_mip_level(c->stream, s->texels.as<uint32_t>(), s->htex[i].off[l - 1], s->htex[i].w[l - 1], s->htex[i].h[l - 1],
 			                     s->htex[i].off[l], s->htex[i].w[l], s->htex[i].h[l], s->htex[i].srgb, c->dDecode, c->dThresh);
 	}
-	for (auto& ti : tinfo) ti.alphaOff = 0xffffffffu;
+	for (const Pack& p : packs)
+		vkr_launch_pack_chain(c->stream, s->texels.as<uint32_t>() + s->htex[p.rgb].off[0], s->texels.as<uint32_t>() + s->htex[p.a].off[0],
+		                      s->texels.as<uint32_t>() + s->htex[p.id].off[0], chain_texels(p.id));
 
 	// ---- materials: binding table + whether the alpha test can ever discard
 	std::vector<int> lowAlpha(d->textureCount, -1);
@@ -640,6 +678,7 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 			lowAlpha[at] = low;
 		}
 		mi.alphaTest = (uint32_t)lowAlpha[at];
+		mi.packNM = matPack[i].first; mi.packAR = matPack[i].second;
 		if (mi.alphaTest) s->anyAlphaTest = true;
 	}
 	if ((rc = upload(s->mat, minfo.data(), minfo.size() * sizeof(MatInfo)))) return fail(rc);
@@ -650,16 +689,14 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 			if (!minfo[i].alphaTest) continue;
 			TexInfo& ti = tinfo[minfo[i].tex[3]];
 			if (ti.alphaOff != 0xffffffffu) continue;
-			const HostTex& h = s->htex[minfo[i].tex[3]];
 			ti.alphaOff = (uint32_t)bytes;
-			bytes += (uint64_t)h.off[h.levels - 1] + (uint64_t)h.w[h.levels - 1] * h.h[h.levels - 1] - h.off[0];
+			bytes += chain_texels(minfo[i].tex[3]);
 		}
 		if ((rc = s->alphaTexels.ensure(bytes ? bytes : 4))) return fail(rc);
 		for (uint32_t t = 0; t < d->textureCount; t++) {
 			if (tinfo[t].alphaOff == 0xffffffffu) continue;
 			const HostTex& h = s->htex[t];
-			const uint32_t n = h.off[h.levels - 1] + h.w[h.levels - 1] * h.h[h.levels - 1] - h.off[0];
-			vkr_launch_extract_alpha(c->stream, s->texels.as<uint32_t>() + h.off[0], s->alphaTexels.as<uint8_t>() + tinfo[t].alphaOff, n);
+			vkr_launch_extract_alpha(c->stream, s->texels.as<uint32_t>() + h.off[0], s->alphaTexels.as<uint8_t>() + tinfo[t].alphaOff, chain_texels(t));
 		}
 	}
 	if ((rc = upload(s->tex, tinfo.data(), tinfo.size() * sizeof(TexInfo)))) return fail(rc);
@@ -673,7 +710,7 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 	dv.tex = s->tex.as<TexInfo>(); dv.mat = s->mat.as<MatInfo>(); dv.texels = s->texels.as<uint32_t>(); dv.alphaTexels = s->alphaTexels.as<uint8_t>();
 	dv.srgbDecode = c->dDecode; dv.srgbThresh = c->dThresh;
 	dv.nTri = (uint32_t)nTri; dv.nTriOpaque = (uint32_t)nTriOpaque; dv.nVert = (uint32_t)nVert;
-	dv.nTex = d->textureCount; dv.nMat = d->materialCount;
+	dv.nTex = (uint32_t)s->htex.size(); dv.nMat = d->materialCount;
 	*out = s;
 	return VKR_OK;
 }

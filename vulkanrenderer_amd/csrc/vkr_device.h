@@ -22,21 +22,27 @@ static inline double vkr_guard_band(uint32_t W, uint32_t H) { return ((W > H ? W
 struct Mat4 { float m[16]; };  // column-major, glm::mat4
 
 // One texture: all mip levels in the scene's texel pool (RGBA8, one u32 per texel).
-struct TexInfo {
-	uint32_t offset[VKR_MAX_LEVELS]; // texel offset of each level in the pool
-	uint16_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS];
+struct alignas(16) TexInfo {
+	// header: what a fetch needs before it knows the level (one 16-byte load)
+	uint32_t wh0;      // level-0 width | height << 16
 	int32_t levels;
 	int32_t srgb;
 	uint32_t alphaOff; // level-0 offset of this texture's chain in the alpha byte pool, ~0u if it has none
+	uint32_t offset[VKR_MAX_LEVELS]; // texel offset of each level in the pool
+	uint16_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS];
 };
 
 // Material -> the five bindings of the material descriptor set
 // (main/main.cpp:770-846): 0 baseColor, 1 metalness, 2 roughness,
 // 3 alphaMask (baseColor when absent), 4 normalMap.
+// packNM / packAR: when the four shaded textures of the material have one
+// size, two repacked chains built at scene creation hold (normal.rgb,
+// metalness.r) and (baseColor.rgb, roughness.r) per texel, so shading takes
+// two trilinear fetches instead of four; ~0u when the material has none.
 struct MatInfo {
 	uint32_t tex[5];
 	uint32_t alphaTest; // 1 if the alpha texture holds any texel with alpha < 128
-	uint32_t _pad[2];
+	uint32_t packNM, packAR;
 };
 
 // Screen-space sub-triangle produced by triangle setup (64 bytes).
@@ -342,7 +348,7 @@ __device__ __forceinline__ float vkr_rho2_wh(float tw, float th, const float d[4
 	float ry = fmaf(ny, ny, nx * nx);
 	return (rx > ry) ? rx : ry;
 }
-__device__ __forceinline__ float vkr_rho2(const TexInfo& t, const float d[4]) { return vkr_rho2_wh((float)t.w[0], (float)t.h[0], d); }
+__device__ __forceinline__ float vkr_rho2(const TexInfo& t, const float d[4]) { return vkr_rho2_wh((float)(t.wh0 & 0xffffu), (float)(t.wh0 >> 16), d); }
 
 __device__ __forceinline__ int vkr_wrap(int i, int n)
 {
@@ -390,7 +396,7 @@ struct TexTaps {
 
 __device__ __forceinline__ bool vkr_same_dims(const TexInfo& t, const TexTaps& tp)
 {
-	return t.w[0] == tp.w0 && t.h[0] == tp.h0 && t.levels == tp.levels;
+	return t.wh0 == (tp.w0 | (tp.h0 << 16)) && t.levels == tp.levels;
 }
 
 __device__ __forceinline__ void vkr_make_taps_wh(uint32_t w0, uint32_t h0, int levels, float u, float v, const float d[4], TexTaps& tp)
@@ -411,7 +417,7 @@ __device__ __forceinline__ void vkr_make_taps_wh(uint32_t w0, uint32_t h0, int l
 }
 __device__ __forceinline__ void vkr_make_taps(const TexInfo& t, float u, float v, const float d[4], TexTaps& tp)
 {
-	vkr_make_taps_wh(t.w[0], t.h[0], t.levels, u, v, d, tp);
+	vkr_make_taps_wh(t.wh0 & 0xffffu, t.wh0 >> 16, t.levels, u, v, d, tp);
 }
 
 // texel offset of level lv of a full mip chain that starts at off0 (levels are stored back to back)
