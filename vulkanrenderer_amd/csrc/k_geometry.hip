@@ -204,7 +204,6 @@ __device__ __forceinline__ bool tri_front(const SetupArgs& a, uint32_t t, TriFro
 	if ((c0.z > c0.w) & (c1.z > c1.w) & (c2.z > c2.w)) ok = false;
 	if (!ok) return false;
 	if (!vkr_tri_planes(c0, c1, c2, a.view.W, a.view.H, f.pl)) return false;
-	a.planes[t] = f.pl; // once per triangle instead of once per shaded pixel
 	const bool isAlphaMesh = t >= a.sc.nTriOpaque;
 	f.cull = isAlphaMesh ? a.cullAlpha : a.cullOpaque;
 	f.prim = a.useOrderB ? a.sc.orderB[t] : t;
@@ -240,9 +239,11 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 	const uint32_t lane = threadIdx.x & 63;
 	bool emit = false, queue = false;
 	SubTri rec; uint2 tiles = make_uint2(0, 0);
+	TriPlanes rec_planes;
 	if (t < a.first + a.count) {
 		TriFront f;
 		if (tri_front(a, t, f)) {
+			rec_planes = f.pl;
 			if (f.needClip) {
 				queue = true;
 			} else {
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 	const uint32_t slot = t - a.first;
 	if (t < a.first + a.count) {
 		// bit 31 of the second word: alpha-tested (bin fill then needs nothing else from the record)
-		if (emit) { a.recs[slot] = rec; a.recTiles[slot] = make_uint2(tiles.x, tiles.y | ((rec.flags & VKR_ST_ALPHA) ? 0x80000000u : 0u)); }
+		// the interpolation planes: once per drawn triangle instead of once per shaded pixel
+		if (emit) { a.planes[t] = rec_planes; a.recs[slot] = rec; a.recTiles[slot] = make_uint2(tiles.x, tiles.y | ((rec.flags & VKR_ST_ALPHA) ? 0x80000000u : 0u)); }
 		else a.recTiles[slot] = make_uint2(0xffffffffu, 0u);
 	}
 	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
@@ -281,18 +283,22 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 	// ~6 G/s.)
 	const bool small = nt >= 1 && nt <= 8;
 	const uint32_t abit = (emit && (rec.flags & VKR_ST_ALPHA)) ? 0x80000000u : 0u;
+	// the record's index in each of its tiles (row-major over its tile rectangle), kept in registers until the
+	// group's bases are known: bit 31 = index inside the group, to be completed
+	uint32_t vloc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	if (small) {
-		uint32_t k = 0;
-		for (uint32_t ty = ty0; ty <= ty1; ty++)
-			for (uint32_t tx = tx0; tx <= tx1; tx++, k++) {
+		uint32_t tx = tx0, ty = ty0;
+#pragma unroll
+		for (uint32_t k = 0; k < 8; k++) {
+			if (k < nt) {
 				const uint32_t tile = ty * a.view.tilesX + tx, key = tile | abit;
 				const uint32_t h = (tile ^ (tile >> 7) ^ (abit >> 23)) & (SETUP_TABLE - 1u);
 				const uint32_t prev = atomicCAS(&sTag[h], 0xffffffffu, key);
-				uint32_t v;
-				if (prev == 0xffffffffu || prev == key) v = atomicAdd(&sCnt[h], 1u) | 0x80000000u;
-				else v = atomicAdd(&(abit ? a.tileCountA : a.tileCount)[tile], 1u);
-				a.recLocal[(size_t)slot * 8 + k] = v;
+				if (prev == 0xffffffffu || prev == key) vloc[k] = atomicAdd(&sCnt[h], 1u) | 0x80000000u;
+				else vloc[k] = atomicAdd(&(abit ? a.tileCountA : a.tileCount)[tile], 1u);
+				if (++tx > tx1) { tx = tx0; ty++; }
 			}
+		}
 	}
 	__syncthreads();
 	for (uint32_t h = threadIdx.x; h < SETUP_TABLE; h += blockDim.x) {
@@ -301,16 +307,21 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 	}
 	__syncthreads();
 	if (small) {
-		uint32_t k = 0;
-		for (uint32_t ty = ty0; ty <= ty1; ty++)
-			for (uint32_t tx = tx0; tx <= tx1; tx++, k++) {
-				const uint32_t v = a.recLocal[(size_t)slot * 8 + k];
-				if (v & 0x80000000u) {
+		uint32_t tx = tx0, ty = ty0;
+#pragma unroll
+		for (uint32_t k = 0; k < 8; k++) {
+			if (k < nt) {
+				if (vloc[k] & 0x80000000u) {
 					const uint32_t tile = ty * a.view.tilesX + tx;
 					const uint32_t h = (tile ^ (tile >> 7) ^ (abit >> 23)) & (SETUP_TABLE - 1u);
-					a.recLocal[(size_t)slot * 8 + k] = sBase[h] + (v & 0x7fffffffu);
+					vloc[k] = sBase[h] + (vloc[k] & 0x7fffffffu);
 				}
+				if (++tx > tx1) { tx = tx0; ty++; }
 			}
+		}
+		uint4* out = (uint4*)(a.recLocal + (size_t)slot * 8);
+		out[0] = make_uint4(vloc[0], vloc[1], vloc[2], vloc[3]);
+		if (nt > 4) out[1] = make_uint4(vloc[4], vloc[5], vloc[6], vloc[7]);
 	}
 	// records that touch many tiles: queued for k_count_big / k_bin_fill_big (one wavefront per record; they come in
 	// runs - the near-field triangles of a mesh - and would otherwise pile up in a few wavefronts)
@@ -332,6 +343,7 @@ __global__ __launch_bounds__(64) void k_setup_clip(SetupArgs a)
 		const uint32_t t = a.clipQueue[q];
 		TriFront f;
 		if (!tri_front(a, t, f)) continue;
+		a.planes[t] = f.pl;
 		const double hW = (double)a.view.W * 0.5, hH = (double)a.view.H * 0.5;
 		setup_clipped(a, f.c0, f.c1, f.c2, f.pl, f.prim, f.flags, f.cull, hW, hH);
 	}
