@@ -371,28 +371,48 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
                                                       uint32_t* __restrict__ offset, uint32_t* __restrict__ cursor, uint32_t nTiles,
                                                       uint32_t cap, uint32_t* overflow, uint32_t* statusOut)
 {
-	__shared__ uint32_t wsum[16];
+	// 8192 tiles per round: the 24 loads of a thread are issued together, the eight 1024-wide scans run from
+	// registers and meet in one barrier (a round per 1024 tiles is three barriers and a load round trip each)
+	__shared__ uint32_t wsum[8][16];
 	__shared__ uint32_t carry;
 	uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	if (tid == 0) carry = 0;
 	__syncthreads();
-	for (uint32_t base = 0; base < nTiles; base += 1024) {
-		uint32_t i = base + tid;
-		uint32_t v = (i < nTiles) ? count[i] + countA[i] + countBig[i] : 0u;
-		uint32_t s = v; // inclusive scan in the wave
+	for (uint32_t base = 0; base < nTiles; base += 8192) {
+		uint32_t v[8], s[8];
 #pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			uint32_t n = __shfl_up(s, d, 64);
-			if ((int)lane >= d) s += n;
+		for (int j = 0; j < 8; j++) {
+			const uint32_t i = base + j * 1024 + tid;
+			v[j] = (i < nTiles) ? count[i] + countA[i] + countBig[i] : 0u;
 		}
-		if (lane == 63) wsum[wid] = s;
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			uint32_t t = v[j]; // inclusive scan in the wave
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				uint32_t n = __shfl_up(t, d, 64);
+				if ((int)lane >= d) t += n;
+			}
+			s[j] = t;
+			if (lane == 63) wsum[j][wid] = t;
+		}
 		__syncthreads();
-		uint32_t wpre = 0;
-		for (uint32_t w = 0; w < wid; w++) wpre += wsum[w];
-		uint32_t excl = carry + wpre + s - v;
-		if (i < nTiles) { offset[i] = excl; cursor[i] = 0; }
+		uint32_t running = carry;
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			uint32_t wpre = 0, tot = 0;
+#pragma unroll
+			for (uint32_t w = 0; w < 16; w++) {
+				const uint32_t x = wsum[j][w];
+				if (w < wid) wpre += x;
+				tot += x;
+			}
+			const uint32_t i = base + j * 1024 + tid;
+			if (i < nTiles) { offset[i] = running + wpre + s[j] - v[j]; cursor[i] = 0; }
+			running += tot;
+		}
 		__syncthreads();
-		if (tid == 1023) carry = excl + v;
+		if (tid == 0) carry = running;
 		__syncthreads();
 	}
 	if (tid == 0) {
