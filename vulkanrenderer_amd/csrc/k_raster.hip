@@ -140,10 +140,15 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 	const uint32_t n = (end - beg) - nA;
 	if (MODE == RASTER_VIS && tid == 0 && nA) sAnyAlpha = 1;
 
-	for (uint32_t base = 0; base < n; base += 256) {
+	// 1, 2 or 4 lanes share one bin entry, so that a short bin (tens of entries per tile is the rule) still
+	// fills the workgroup: a small sub-triangle covers a handful of pixels per row, and with one entry per
+	// lane nine lanes in ten would idle.  The lanes of a group take every group-th column of the bounding box.
+	const uint32_t logG = n <= 64u ? 2u : n <= 128u ? 1u : 0u, G = 1u << logG;
+	const uint32_t sub = lane & (G - 1u);
+	for (uint32_t base = 0; base < n; base += 256u >> logG) {
 		// entries are dealt to the four wavefronts round-robin, so a short bin still spreads its
 		// large (wave-cooperative) sub-triangles over all of them
-		const uint32_t i = base + (tid & 63u) * 4u + (tid >> 6);
+		const uint32_t i = base + (lane >> logG) * 4u + (tid >> 6);
 		bool has = i < n;
 		SubTri s;
 		int bx0 = 0, by0 = 0, bx1 = -1, by1 = -1;
@@ -163,19 +168,21 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 
 		if (nonEmpty && !big) {
 			EdgeSetup E;
-			edge_setup(s, bx0, by0, E);
+			edge_setup(s, bx0 + (int)sub, by0, E);
+			const double gd = (double)G;
+			const double gx0 = E.sx0 * gd, gx1 = E.sx1 * gd, gx2 = E.sx2 * gd;
 			for (int py = by0; py <= by1; py++) {
 				double e0 = E.e0, e1 = E.e1, e2 = E.e2;
-				for (int px = bx0; px <= bx1; px++) {
+				for (int px = bx0 + (int)sub; px <= bx1; px += (int)G) {
 					if (edges_inside(e0, e1, e2)) fragment<MODE>(tb64, tb32, (py - oy) * VKR_TILE + (px - ox), s, px, py);
-					e0 += E.sx0; e1 += E.sx1; e2 += E.sx2;
+					e0 += gx0; e1 += gx1; e2 += gx2;
 				}
 				E.e0 += E.sy0; E.e1 += E.sy1; E.e2 += E.sy2;
 			}
 		}
 
 		// wave-cooperative pass over the big sub-triangles of this wave
-		unsigned long long mask = __ballot(big);
+		unsigned long long mask = __ballot(big && sub == 0);
 		while (mask) {
 			const int src = __ffsll((long long)mask) - 1;
 			mask &= mask - 1;
