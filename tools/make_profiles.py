@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Turns the counter_collection.csv files of separate `rocprofv3 --pmc` passes into the two per-kernel summaries kept
+under profiles/ (HBM traffic, vector-ALU utilisation).
+
+  python3 tools/make_profiles.py --tag r01e --out gpurun_out --fetch DIR --write DIR --valu DIR --valu2 DIR
+
+Every DIR is the -d directory of one pass over `python3 tools/stage_times.py --poses 0 --reps N`:
+  --fetch   --pmc FETCH_SIZE
+  --write   --pmc WRITE_SIZE
+  --valu    --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM
+  --valu2   --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 TA_TA_BUSY_sum
+"""
+import argparse, collections, csv, glob, json, os
+
+
+def per_kernel(d):
+    """{kernel: {counter: [value per dispatch]}}; rows of one dispatch and counter are summed first."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if not k.startswith("k_"):
+                continue
+            acc[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return {k: {c: list(v.values()) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+def avg(x):
+    return sum(x) / len(x) if x else 0.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--out", default="gpurun_out")
+    ap.add_argument("--fetch"); ap.add_argument("--write"); ap.add_argument("--valu"); ap.add_argument("--valu2")
+    ap.add_argument("--width", type=int, default=3840); ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--workload", default="SunTemple-proxy v1 (256^2 textures), deferred, 3840x2160, fly-through pose 0")
+    a = ap.parse_args()
+    if a.fetch and a.write:
+        fe, wr = per_kernel(a.fetch), per_kernel(a.write)
+        ks = {}
+        for k in sorted(set(fe) | set(wr)):
+            f = fe.get(k, {}).get("FETCH_SIZE", [])
+            w = wr.get(k, {}).get("WRITE_SIZE", [])
+            ks[k] = {"FETCH_SIZE_KB_avg": round(avg(f), 1), "launches_FETCH_SIZE": len(f), "WRITE_SIZE_KB_avg": round(avg(w), 1),
+                     "launches_WRITE_SIZE": len(w), "hbm_bytes_per_launch_corrected": int(round((2 * avg(f) + avg(w)) * 1024))}
+        json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 tools/stage_times.py --poses 0 --reps 3 --tex-size 256",
+                   "workload": a.workload, "width": a.width, "height": a.height,
+                   "note": "FETCH_SIZE and WRITE_SIZE are in KB; FETCH_SIZE on gfx950 tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section), hence the doubling",
+                   "kernels": ks}, open(os.path.join(a.out, a.tag + "_pmc_traffic_4k.json"), "w"), indent=1)
+    if a.valu and a.valu2:
+        v1, v2 = per_kernel(a.valu), per_kernel(a.valu2)
+        ks = {}
+        for k in sorted(set(v1) & set(v2)):
+            c1, c2 = v1[k], v2[k]
+            waves = avg(c1.get("SQ_WAVES", []))
+            gui = avg(c2.get("GRBM_GUI_ACTIVE", []))
+            cyc = gui / 8.0  # summed over the 8 XCDs
+            if not waves or not cyc:
+                continue
+            f64 = sum(avg(c2.get(n, [])) for n in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
+            e = {"waves": int(waves), "valu_instructions_per_wave": round(avg(c1.get("SQ_INSTS_VALU", [])) / waves, 1),
+                 "salu_instructions_per_wave": round(avg(c1.get("SQ_INSTS_SALU", [])) / waves, 1),
+                 "vmem_instructions_per_wave": round(avg(c1.get("SQ_INSTS_VMEM", [])) / waves, 1),
+                 "lds_instructions_per_wave": round(avg(c1.get("SQ_INSTS_LDS", [])) / waves, 1),
+                 "kernel_cycles": int(cyc),
+                 "valu_busy_frac": round(avg(c1.get("SQ_ACTIVE_INST_VALU", [])) * 4.0 / (1024.0 * cyc), 3),
+                 "f64_instructions_per_wave": round(f64 / waves, 1)}
+            if "TA_TA_BUSY_sum" in c2:
+                e["ta_busy_frac"] = round(avg(c2["TA_TA_BUSY_sum"]) / (256.0 * cyc), 3)
+            ks[k] = e
+        json.dump({"command": "two passes: rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM and --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 TA_TA_BUSY_sum, each with --output-format csv -- python3 tools/stage_times.py --poses 0 --reps 2",
+                   "workload": a.workload, "width": a.width, "height": a.height,
+                   "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); SQ_ACTIVE_INST_* count quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs; a value slightly above 1 means every issue slot was taken (a transcendental occupies two). ta_busy_frac = TA_TA_BUSY_sum / (256 texture-address units x kernel cycles)",
+                   "kernels": ks}, open(os.path.join(a.out, a.tag + "_pmc_valu_4k.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

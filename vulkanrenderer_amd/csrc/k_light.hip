@@ -43,10 +43,11 @@ __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 	vkr_load_srgb_table(sT, a.srgbThresh);
 	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
-	// a workgroup shades 16x16 pixels, each wavefront an 8x8 block: the pixels of a wavefront mostly lie on
-	// one surface, which is what lets whole wavefronts skip the lights behind it (below)
+	// a workgroup shades 32x8 pixels, each wavefront an 8x8 block: the pixels of a wavefront mostly lie on
+	// one surface, which is what lets whole wavefronts skip the lights behind it (below), and a workgroup's
+	// rows are whole 128-byte lines of the depth buffer (16 pixels wide, half of each line was fetched twice)
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-	const uint32_t x = blockIdx.x * 16u + (wv & 1u) * 8u + (lane & 7u), y = blockIdx.y * 16u + (wv >> 1) * 8u + (lane >> 3);
+	const uint32_t x = blockIdx.x * 32u + wv * 8u + (lane & 7u), y = blockIdx.y * 8u + (lane >> 3);
 	if (x >= rw || y >= rh) return;
 	const uint32_t p = y * rw + x;
 	const float depth = a.depth[p];
@@ -231,7 +232,7 @@ void vkr_launch_deferred_light(hipStream_t s, const LightArgs& a)
 	bool same = true;
 	for (int i = 1; i < VKR_NUM_LIGHTS_K; i++)
 		for (int c = 0; c < 3; c++) same = same && a.lightCol[i][c] == a.lightCol[0][c];
-	const dim3 grid((a.view.x1 - a.view.x0 + 15) / 16, (a.view.y1 - a.view.y0 + 15) / 16);
+	const dim3 grid((a.view.x1 - a.view.x0 + 31) / 32, (a.view.y1 - a.view.y0 + 7) / 8);
 	if (same) hipLaunchKernelGGL((k_deferred_light<true>), grid, dim3(256), 0, s, a);
 	else hipLaunchKernelGGL((k_deferred_light<false>), grid, dim3(256), 0, s, a);
 }
