@@ -110,7 +110,7 @@ __device__ __forceinline__ void bcast_subtri(const SubTri& s, int bx0, int by0, 
 
 // Every sub-triangle of the tile's bin that needs no alpha test.  In
 // RASTER_VIS mode alpha-tested sub-triangles are left to k_raster_alpha and
-// such tiles are appended to alphaTiles.
+// such tiles are flagged in alphaTiles.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 		else if (MODE == RASTER_SHADOW) a.depthOut[p] = u2f(tb32[i]);
 		else a.countOut[p] = (uint8_t)min(tb32[i], 255u); // INCREMENT_AND_CLAMP, main/main.cpp:2783
 	}
-	if (MODE == RASTER_VIS && tid == 0 && sAnyAlpha) a.alphaTiles[atomicAdd(a.alphaTileCount, 1u)] = tile;
+	if (MODE == RASTER_VIS && tid == 0) a.alphaTiles[tile] = (uint32_t)sAnyAlpha;
 }
 
 // ---------------------------------------------------------------------------
@@ -316,9 +316,8 @@ __device__ __forceinline__ float alpha_fetch_finish(const AlphaFetch& f, const A
 
 __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a)
 {
-	const uint32_t nAlpha = min(a.alphaTileCount[0], a.view.tilesX * a.view.tilesY);
-	if (blockIdx.x / 4 >= nAlpha) return;
-	const uint32_t tile = a.alphaTiles[blockIdx.x / 4];
+	const uint32_t tile = blockIdx.x / 4;
+	if (!a.alphaTiles[tile]) return;
 	const int qx = (int)(blockIdx.x & 1) * 16, qy = (int)((blockIdx.x >> 1) & 1) * 16; // the quadrant, tile-local
 	__shared__ AlphaCover sCov[ALPHA_STAGE];
 	__shared__ AlphaAttr sAttr[ALPHA_STAGE];
@@ -368,10 +367,9 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 				tri_bbox(s, bx0, by0, bx1, by1);
 				bx0 = max(bx0, ox + qx); by0 = max(by0, oy + qy); bx1 = min(bx1, min(ex, ox + qx + 15)); by1 = min(by1, min(ey, oy + qy + 15));
 				if (bx0 <= bx1 && by0 <= by1) {
-					// alpha-tested passes submit in order A, so prim indexes sc.tri directly
-					const uint32_t i0 = a.sc.tri[3 * (size_t)s.prim + 0], i1 = a.sc.tri[3 * (size_t)s.prim + 1],
-					               i2 = a.sc.tri[3 * (size_t)s.prim + 2];
+					// alpha-tested passes submit in order A, so prim indexes the per-triangle tables directly
 					const TriPlanes pl = a.planes[s.prim];
+					const AlphaAux ax = a.sc.alphaAux[s.prim];
 					{
 						const uint32_t slot = atomicAdd(&sCount, 1u);
 						AlphaCover& c = sCov[slot];
@@ -387,11 +385,8 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 						AlphaAttr& t = sAttr[slot];
 #pragma unroll
 						for (int k = 0; k < 3; k++) { t.a[k] = pl.a[k]; t.b[k] = pl.b[k]; t.c[k] = pl.c[k]; }
-						t.t0 = make_float2(a.sc.uv[2 * (size_t)i0], a.sc.uv[2 * (size_t)i0 + 1]);
-						t.t1 = make_float2(a.sc.uv[2 * (size_t)i1], a.sc.uv[2 * (size_t)i1 + 1]);
-						t.t2 = make_float2(a.sc.uv[2 * (size_t)i2], a.sc.uv[2 * (size_t)i2 + 1]);
-						const TexInfo& tex = a.sc.tex[a.sc.mat[a.sc.triMat[s.prim]].tex[3]];
-						t.off0 = tex.alphaOff; t.w0 = tex.wh0 & 0xffffu; t.h0 = tex.wh0 >> 16; t.levels = tex.levels;
+						t.t0 = ax.t0; t.t1 = ax.t1; t.t2 = ax.t2;
+						t.off0 = ax.off0; t.w0 = ax.wh0 & 0xffffu; t.h0 = ax.wh0 >> 16; t.levels = ax.levels;
 					}
 				}
 			}

@@ -112,3 +112,27 @@ void vkr_launch_pack_chain(hipStream_t s, const uint32_t* rgb, const uint32_t* a
 	if (!n) return;
 	hipLaunchKernelGGL(k_pack_chain, dim3((n + 255) / 256), dim3(256), 0, s, rgb, a, out, n);
 }
+
+// ---------------------------------------------------------------------------
+// AlphaAux table: one record per triangle (submission order A).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_alpha_aux(SceneDev sc, AlphaAux* __restrict__ out)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= sc.nTri) return;
+	const uint32_t i0 = sc.tri[3 * (size_t)t + 0], i1 = sc.tri[3 * (size_t)t + 1], i2 = sc.tri[3 * (size_t)t + 2];
+	const TexInfo& tex = sc.tex[sc.mat[sc.triMat[t]].tex[3]];
+	AlphaAux x;
+	x.t0 = make_float2(sc.uv[2 * (size_t)i0], sc.uv[2 * (size_t)i0 + 1]);
+	x.t1 = make_float2(sc.uv[2 * (size_t)i1], sc.uv[2 * (size_t)i1 + 1]);
+	x.t2 = make_float2(sc.uv[2 * (size_t)i2], sc.uv[2 * (size_t)i2 + 1]);
+	x.off0 = tex.alphaOff; x.wh0 = tex.wh0; x.levels = tex.levels;
+	x._pad[0] = x._pad[1] = x._pad[2] = 0u;
+	out[t] = x;
+}
+
+void vkr_launch_alpha_aux(hipStream_t s, const SceneDev& sc, AlphaAux* out)
+{
+	if (!sc.nTri) return;
+	hipLaunchKernelGGL(k_alpha_aux, dim3((sc.nTri + 255) / 256), dim3(256), 0, s, sc, out);
+}

@@ -118,7 +118,7 @@ struct HostTex { uint32_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS], off[VKR_MAX_LEVE
 
 struct vkr_scene {
 	vkr_context* ctx = nullptr;
-	DevBuf pos, uv, tcomp, tbn, tri, triMat, orderB, tex, mat, texels, alphaTexels;
+	DevBuf pos, uv, tcomp, tbn, tri, triMat, orderB, tex, mat, texels, alphaTexels, alphaAux;
 	SceneDev dev;
 	std::vector<HostTex> htex;
 	uint64_t nTri = 0, nVert = 0, texelCount = 0;
@@ -484,7 +484,7 @@ extern "C" void vkr_scene_destroy(vkr_scene* s)
 {
 	if (!s) return;
 	if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
-	DevBuf* bufs[] = { &s->pos, &s->uv, &s->tcomp, &s->tbn, &s->tri, &s->triMat, &s->orderB, &s->tex, &s->mat, &s->texels, &s->alphaTexels };
+	DevBuf* bufs[] = { &s->pos, &s->uv, &s->tcomp, &s->tbn, &s->tri, &s->triMat, &s->orderB, &s->tex, &s->mat, &s->texels, &s->alphaTexels, &s->alphaAux };
 	for (DevBuf* b : bufs) b->release();
 	delete s;
 }
@@ -700,10 +700,7 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 		}
 	}
 	if ((rc = upload(s->tex, tinfo.data(), tinfo.size() * sizeof(TexInfo)))) return fail(rc);
-	{
-		hipError_t e = hipStreamSynchronize(c->stream);
-		if (e != hipSuccess) return fail(set_error(VKR_E_DEVICE, "mip generation: %s", hipGetErrorString(e)));
-	}
+	if ((rc = s->alphaAux.ensure(nTri ? nTri * sizeof(AlphaAux) : sizeof(AlphaAux)))) return fail(rc);
 	SceneDev& dv = s->dev;
 	dv.pos = s->pos.as<float>(); dv.uv = s->uv.as<float>(); dv.tcomp = s->tcomp.as<uint32_t>(); dv.tbn = s->tbn.as<float4>();
 	dv.tri = s->tri.as<uint32_t>(); dv.triMat = s->triMat.as<uint32_t>(); dv.orderB = s->orderB.as<uint32_t>();
@@ -711,6 +708,12 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 	dv.srgbDecode = c->dDecode; dv.srgbThresh = c->dThresh;
 	dv.nTri = (uint32_t)nTri; dv.nTriOpaque = (uint32_t)nTriOpaque; dv.nVert = (uint32_t)nVert;
 	dv.nTex = (uint32_t)s->htex.size(); dv.nMat = d->materialCount;
+	dv.alphaAux = s->alphaAux.as<AlphaAux>();
+	vkr_launch_alpha_aux(c->stream, dv, s->alphaAux.as<AlphaAux>());
+	{
+		hipError_t e = hipStreamSynchronize(c->stream);
+		if (e != hipSuccess) return fail(set_error(VKR_E_DEVICE, "mip generation: %s", hipGetErrorString(e)));
+	}
 	*out = s;
 	return VKR_OK;
 }
@@ -793,7 +796,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if ((rc = c->binList.ensure((size_t)binCap * 4))) return rc;
 	if (g.keys && (rc = c->binKeys.ensure((size_t)binCap * 4))) return rc;
 	c->recCap = recCap; c->binCap = binCap;
-	uint32_t* counters = c->counters.as<uint32_t>(); // [0] recCount, [1] overflow, [2] alpha tile count, [3] clip queue length, [4] big-record queue length
+	uint32_t* counters = c->counters.as<uint32_t>(); // [0] recCount, [1] overflow, [2] unused, [3] clip queue length, [4] big-record queue length
 	ZeroArgs z;
 	z.counters = counters; z.tiles0 = c->tileCount.as<uint32_t>(); z.tiles1 = c->tileCountA.as<uint32_t>();
 	z.tiles2 = c->tileCountBig.as<uint32_t>(); z.nTiles = nTiles;
@@ -838,7 +841,7 @@ static void fill_raster_args(vkr_context* c, const vkr_scene* s, const ViewDev& 
 	r.sc = s->dev; r.view = view; r.clip = c->clip.as<float4>(); r.planes = c->planes.as<TriPlanes>(); r.recs = c->recs.as<SubTri>();
 	r.tileOffset = c->tileOffset.as<uint32_t>(); r.tileCount = c->tileCount.as<uint32_t>(); r.tileCountA = c->tileCountA.as<uint32_t>(); r.binList = c->binList.as<uint32_t>(); r.binCap = c->binCap;
 	r.vis = nullptr; r.depthOut = nullptr; r.countOut = nullptr;
-	r.alphaTiles = c->tileFlags.as<uint32_t>(); r.alphaTileCount = c->counters.as<uint32_t>() + 2; r.alphaPass = 0;
+	r.alphaTiles = c->tileFlags.as<uint32_t>(); r.alphaPass = 0;
 }
 
 static int copy_out(vkr_context* c, void* dst, const void* src, size_t bytes)

@@ -45,6 +45,16 @@ struct MatInfo {
 	uint32_t packNM, packAR;
 };
 
+// Texture coordinates of a triangle's vertices and the description of the texture its alpha test samples
+// (binding 3 of its material), gathered once at scene creation: the alpha pass reads one record instead of
+// walking triangle -> vertices and triangle -> material -> texture.
+struct alignas(16) AlphaAux {
+	float2 t0, t1, t2;
+	uint32_t off0, wh0; // chain offset in the alpha byte pool; level-0 width | height << 16
+	int32_t levels;
+	uint32_t _pad[3];
+};
+
 // Screen-space sub-triangle produced by triangle setup (64 bytes).
 struct SubTri {
 	int32_t X0, Y0, X1, Y1, X2, Y2; // snapped to 1/256 px, orientation positive
@@ -68,6 +78,7 @@ struct SceneDev {
 	const MatInfo* mat;
 	const uint32_t* texels;  // texel pool
 	const uint8_t* alphaTexels; // alpha bytes of the textures an alpha test samples, same level layout per chain
+	const struct AlphaAux* alphaAux; // per triangle (order A): what an alpha test needs besides the interpolation planes
 	const float* srgbDecode; // 256
 	const float* srgbThresh; // 255
 	uint32_t nTri, nTriOpaque, nVert, nTex, nMat;

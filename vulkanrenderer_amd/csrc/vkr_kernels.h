@@ -70,8 +70,7 @@ struct RasterArgs {
 	unsigned long long* vis; // RASTER_VIS: rect-sized visibility buffer
 	float* depthOut;         // RASTER_SHADOW: rect-sized depth
 	uint8_t* countOut;       // RASTER_COUNT: rect-sized saturating counter
-	uint32_t* alphaTiles;    // RASTER_VIS: list of the tiles whose bin holds alpha-tested sub-triangles
-	uint32_t* alphaTileCount; // its length (zeroed by the caller)
+	uint32_t* alphaTiles;    // RASTER_VIS: per tile, 1 if its bin holds alpha-tested sub-triangles (written for every tile)
 	int alphaPass;           // RASTER_VIS: run the alpha-tested second pass
 };
 
@@ -130,6 +129,7 @@ void vkr_launch_mosaic(hipStream_t s, const uint32_t* src, uint32_t srcX0, uint3
 void vkr_launch_mip_level(hipStream_t s, uint32_t* texels, uint32_t srcOff, uint32_t sw, uint32_t sh, uint32_t dstOff,
                           uint32_t dw, uint32_t dh, int srgb, const float* srgbDecode, const float* srgbThresh);
 void vkr_launch_extract_alpha(hipStream_t s, const uint32_t* texels, uint8_t* out, uint32_t n);
+void vkr_launch_alpha_aux(hipStream_t s, const SceneDev& sc, AlphaAux* out);
 void vkr_launch_pack_chain(hipStream_t s, const uint32_t* rgb, const uint32_t* a, uint32_t* out, uint32_t n);
 void vkr_launch_tbn_table(hipStream_t s, const uint32_t* tcomp, float4* out, uint32_t nVert);
 void vkr_launch_fill_u32(hipStream_t s, uint32_t* dst, uint32_t value, size_t n);
