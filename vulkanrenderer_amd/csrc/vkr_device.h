@@ -147,22 +147,24 @@ __device__ __forceinline__ uint32_t vkr_f2h_hw(float f)
 }
 
 // (float)k / 255.0f for k in [0,255] and (float)k / 1023.0f for k in [0,1023]
-// without the division sequence: one Newton step on k * (1/n) is the
-// correctly rounded quotient for every such k (checked exhaustively on the
-// host), so these are bit-identical to the divisions they replace.
+// without the division sequence: with 1/n split into a float and the float
+// nearest to the remainder, fma(k, hi, k * lo) rounds the quotient once, from
+// a value within 2^-48 of it - the correctly rounded quotient for every k of
+// the range (checked against exact rational arithmetic for all 256 / 1024
+// inputs).
 __device__ __forceinline__ float vkr_unorm8(uint32_t k)
 {
-	const float R = 1.0f / 255.0f;
+	const float HI = 0x1.010102p-8f;   // float(1/255)
+	const float LO = -0x1.fdfdfep-33f; // float(1/255 - HI)
 	const float kf = (float)k;
-	const float q = kf * R;
-	return fmaf(fmaf(-q, 255.0f, kf), R, q);
+	return fmaf(kf, HI, kf * LO);
 }
 __device__ __forceinline__ float vkr_unorm10(uint32_t k)
 {
-	const float R = 1.0f / 1023.0f;
+	const float HI = 0x1.004010p-10f;  // float(1/1023)
+	const float LO = 0x1.004010p-40f;  // float(1/1023 - HI)
 	const float kf = (float)k;
-	const float q = kf * R;
-	return fmaf(fmaf(-q, 1023.0f, kf), R, q);
+	return fmaf(kf, HI, kf * LO);
 }
 
 __device__ __forceinline__ float vkr_clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
