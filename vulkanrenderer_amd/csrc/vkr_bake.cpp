@@ -1,0 +1,601 @@
+// vkr_bake.cpp — libvkr_bake.so: OBJ/MTL -> welded, tangent-carrying meshes ->
+// ".comp5892mesh" ("21-tan").  Host code only; compiled with -ffp-contract=off
+// and without FMA so that the double arithmetic of the tangent generator and
+// the float arithmetic of the TBN packer round as the reference tool's do.
+//
+//   load_obj            main-bake/load_model_obj.cpp:16-172 (rapidobj replaced by a text parser)
+//   index_mesh          main-bake/index_mesh.cpp:76-228, :390-471
+//   tangent space       third_party/tgen/src/tgen.cpp:98-258
+//   pack_tbn            main-bake/index_mesh.cpp:178-220
+//   write_model         main-bake/main.cpp:276-389
+//   unique textures     main-bake/main.cpp:426-476, fallbacks :236-251
+#include "../../include/vkr_bake.h"
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return 1;
+}
+
+// ---------------------------------------------------------------------------
+// welding: main-bake/index_mesh.cpp:390-471.  For every soup vertex i not yet
+// merged, every other unmerged vertex whose position, normal and texture
+// coordinate lie within the tolerance of i's (component-wise, compared with
+// i only, not transitively) collapses onto i; output vertices are numbered in
+// the order their first soup vertex appears.  The reference finds the
+// candidates through a hashed grid of cell size ~2*tolerance and its 27
+// neighbours; any search that returns every vertex within the tolerance gives
+// the same result, whatever order it returns them in.
+// ---------------------------------------------------------------------------
+struct Soup {
+	const float* pos; const float* nrm; const float* uv;
+	size_t n;
+};
+
+inline bool mergable(const Soup& s, size_t i, size_t j, float tol)
+{
+	for (int k = 0; k < 3; k++)
+		if (std::fabs(s.pos[3 * i + k] - s.pos[3 * j + k]) > tol) return false;
+	if (s.nrm)
+		for (int k = 0; k < 3; k++)
+			if (std::fabs(s.nrm[3 * i + k] - s.nrm[3 * j + k]) > tol) return false;
+	for (int k = 0; k < 2; k++)
+		if (std::fabs(s.uv[2 * i + k] - s.uv[2 * j + k]) > tol) return false;
+	return true;
+}
+
+struct CellKey {
+	int64_t x, y, z;
+	bool operator==(const CellKey& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct CellHash {
+	size_t operator()(const CellKey& k) const
+	{
+		uint64_t h = (uint64_t)k.x * 0x9E3779B97F4A7C15ull;
+		h ^= (uint64_t)k.y * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+		h ^= (uint64_t)k.z * 0x165667B19E3779F9ull + (h << 6) + (h >> 2);
+		return (size_t)h;
+	}
+};
+
+void weld(const Soup& s, float tol, std::vector<uint32_t>& indices, std::vector<size_t>& firstOf)
+{
+	indices.clear(); firstOf.clear();
+	indices.reserve(s.n); firstOf.reserve(s.n);
+	if (!s.n) return;
+	double mn[3] = { s.pos[0], s.pos[1], s.pos[2] };
+	for (size_t i = 0; i < s.n; i++)
+		for (int k = 0; k < 3; k++) mn[k] = std::min(mn[k], (double)s.pos[3 * i + k]);
+	// cells at least two tolerances wide: vertices within one tolerance sit in the same or an adjacent cell
+	const double cell = tol > 0.0f ? 2.0 * (double)tol : 0.0;
+	auto key_of = [&](size_t i) {
+		CellKey k;
+		if (cell > 0.0) {
+			k.x = (int64_t)std::floor(((double)s.pos[3 * i + 0] - mn[0]) / cell);
+			k.y = (int64_t)std::floor(((double)s.pos[3 * i + 1] - mn[1]) / cell);
+			k.z = (int64_t)std::floor(((double)s.pos[3 * i + 2] - mn[2]) / cell);
+		} else { // zero tolerance: only equal positions can merge (-0 == +0, so key by value, not by bits)
+			auto bits = [](float f) { f += 0.0f; uint32_t u; std::memcpy(&u, &f, 4); return (int64_t)u; };
+			k.x = bits(s.pos[3 * i + 0]); k.y = bits(s.pos[3 * i + 1]); k.z = bits(s.pos[3 * i + 2]);
+		}
+		return k;
+	};
+	std::unordered_map<CellKey, std::vector<uint32_t>, CellHash> grid;
+	grid.reserve(s.n);
+	for (size_t i = 0; i < s.n; i++) grid[key_of(i)].push_back((uint32_t)i);
+
+	const size_t NONE = ~size_t(0);
+	std::vector<size_t> collapse(s.n, NONE);
+	size_t next = 0;
+	const int reach = cell > 0.0 ? 1 : 0;
+	for (size_t i = 0; i < s.n; i++) {
+		if (collapse[i] != NONE) { indices.push_back((uint32_t)collapse[i]); continue; }
+		const size_t to = next++;
+		collapse[i] = to;
+		firstOf.push_back(i);
+		indices.push_back((uint32_t)to);
+		const CellKey c = key_of(i);
+		for (int dz = -reach; dz <= reach; dz++)
+			for (int dy = -reach; dy <= reach; dy++)
+				for (int dx = -reach; dx <= reach; dx++) {
+					auto it = grid.find(CellKey{ c.x + dx, c.y + dy, c.z + dz });
+					if (it == grid.end()) continue;
+					for (uint32_t j : it->second) {
+						if (j == i || collapse[j] != NONE) continue;
+						if (mergable(s, i, j, tol)) collapse[j] = to;
+					}
+				}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// tangent space, in double as tgen does (RealT = double, tgen.h:23)
+// ---------------------------------------------------------------------------
+inline void normalize3(double* v)
+{
+	const double len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+	const double inv = 1.0 / len;
+	v[0] = v[0] * inv; v[1] = v[1] * inv; v[2] = v[2] * inv;
+}
+inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline void cross3(const double* a, const double* b, double* r)
+{
+	r[0] = a[1] * b[2] - a[2] * b[1];
+	r[1] = a[2] * b[0] - a[0] * b[2];
+	r[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// positions/uvs/normals per vertex, indices per corner -> tangent4 per vertex
+void tangent_space(const std::vector<uint32_t>& idx, const std::vector<double>& P, const std::vector<double>& UV,
+                   const std::vector<double>& N, std::vector<double>& tan4)
+{
+	const size_t corners = idx.size(), verts = N.size() / 3;
+	// computeCornerTSpace, tgen.cpp:98-169
+	std::vector<double> cT(corners * 3), cB(corners * 3);
+	for (size_t i = 0; i + 2 < corners; i += 3) {
+		double e3[3][3], e2[3][2];
+		for (size_t j = 0; j < 3; j++) {
+			const size_t v0 = idx[i + j], v1 = idx[i + (j + 1) % 3];
+			for (int k = 0; k < 3; k++) e3[j][k] = P[v1 * 3 + k] - P[v0 * 3 + k];
+			for (int k = 0; k < 2; k++) e2[j][k] = UV[v1 * 2 + k] - UV[v0 * 2 + k];
+		}
+		for (size_t j = 0; j < 3; j++) {
+			const size_t prev = (j + 2) % 3;
+			const double* dP0 = e3[j]; const double* dP1n = e3[prev];
+			const double* dU0 = e2[j]; const double* dU1n = e2[prev];
+			const double denom = (dU0[0] * -dU1n[1] - dU0[1] * -dU1n[0]);
+			const double r = std::fabs(denom) > 1e-10 ? 1.0 / denom : 0.0;
+			const double s0 = -dU1n[1] * r, s1 = -dU0[1] * r, s2 = -dU0[0] * r, s3 = -dU1n[0] * r;
+			for (int k = 0; k < 3; k++) {
+				cT[(i + j) * 3 + k] = dP0[k] * s0 - dP1n[k] * s1;
+				cB[(i + j) * 3 + k] = dP1n[k] * s2 - dP0[k] * s3;
+			}
+		}
+	}
+	// computeVertexTSpace, tgen.cpp:173-207 (the caller passes the index count as the vertex count; only the
+	// first `verts` entries are read afterwards)
+	std::vector<double> vT(verts * 3, 0.0), vB(verts * 3, 0.0);
+	for (size_t i = 0; i < corners; i++) {
+		const size_t v = idx[i];
+		for (int k = 0; k < 3; k++) { vT[v * 3 + k] = cT[i * 3 + k] + vT[v * 3 + k]; vB[v * 3 + k] = cB[i * 3 + k] + vB[v * 3 + k]; }
+	}
+	for (size_t v = 0; v < verts; v++) { normalize3(&vT[v * 3]); normalize3(&vB[v * 3]); }
+	// orthogonalizeTSpace, tgen.cpp:211-233; computeTangent4D, tgen.cpp:237-258
+	tan4.resize(verts * 4);
+	for (size_t v = 0; v < verts; v++) {
+		const double* n = &N[v * 3];
+		double* t = &vT[v * 3]; double* b = &vB[v * 3];
+		const double d = dot3(n, t);
+		for (int k = 0; k < 3; k++) t[k] = t[k] - n[k] * d;
+		normalize3(t);
+		cross3(n, t, b);
+		double c[3];
+		cross3(n, t, c);
+		const double sign = dot3(c, b) > 0.0 ? 1.0 : -1.0;
+		tan4[v * 4 + 0] = t[0]; tan4[v * 4 + 1] = t[1]; tan4[v * 4 + 2] = t[2]; tan4[v * 4 + 3] = sign;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// TBN frame -> quaternion -> 2:10:10:10 (index_mesh.cpp:178-220), with glm's
+// operation order: normalize = v * (1/sqrt(dot)), dot = (x*x + y*y) + z*z
+// ---------------------------------------------------------------------------
+inline void glm_normalize3(const float* a, float* o)
+{
+	const float t0 = a[0] * a[0], t1 = a[1] * a[1], t2 = a[2] * a[2];
+	const float inv = 1.0f / std::sqrt(t0 + t1 + t2);
+	o[0] = a[0] * inv; o[1] = a[1] * inv; o[2] = a[2] * inv;
+}
+
+uint32_t pack_tbn(const float tangent4[4], const float normal[3])
+{
+	const float Tin[3] = { tangent4[0] * tangent4[3], tangent4[1] * tangent4[3], tangent4[2] * tangent4[3] };
+	float T[3], N[3], B[3], c[3];
+	glm_normalize3(Tin, T);
+	glm_normalize3(normal, N);
+	c[0] = N[1] * T[2] - T[1] * N[2];
+	c[1] = N[2] * T[0] - T[2] * N[0];
+	c[2] = N[0] * T[1] - T[0] * N[1];
+	glm_normalize3(c, B);
+	// glm::quat_cast(mat3(T, B, N)), m[column][row]
+	const float m00 = T[0], m01 = T[1], m02 = T[2], m10 = B[0], m11 = B[1], m12 = B[2], m20 = N[0], m21 = N[1], m22 = N[2];
+	const float fx = m00 - m11 - m22, fy = m11 - m00 - m22, fz = m22 - m00 - m11, fw = m00 + m11 + m22;
+	int big = 0; float fb = fw;
+	if (fx > fb) { fb = fx; big = 1; }
+	if (fy > fb) { fb = fy; big = 2; }
+	if (fz > fb) { fb = fz; big = 3; }
+	const float bv = std::sqrt(fb + 1.0f) * 0.5f, mult = 0.25f / bv;
+	float q[4]; // x y z w
+	switch (big) {
+	case 0: q[3] = bv; q[0] = (m12 - m21) * mult; q[1] = (m20 - m02) * mult; q[2] = (m01 - m10) * mult; break;
+	case 1: q[3] = (m12 - m21) * mult; q[0] = bv; q[1] = (m01 + m10) * mult; q[2] = (m20 + m02) * mult; break;
+	case 2: q[3] = (m20 - m02) * mult; q[0] = (m01 + m10) * mult; q[1] = bv; q[2] = (m12 + m21) * mult; break;
+	default: q[3] = (m01 - m10) * mult; q[0] = (m20 + m02) * mult; q[1] = (m12 + m21) * mult; q[2] = bv; break;
+	}
+	const float len = std::sqrt((q[3] * q[3] + q[0] * q[0]) + (q[1] * q[1] + q[2] * q[2]));
+	if (len <= 0.0f) { q[0] = q[1] = q[2] = 0.0f; q[3] = 1.0f; }
+	else { const float ol = 1.0f / len; for (float& v : q) v *= ol; }
+	int maxIndex = 0; float mv = std::fabs(q[0]);
+	for (int i = 1; i < 4; i++) if (std::fabs(q[i]) > mv) { mv = std::fabs(q[i]); maxIndex = i; }
+	if (q[maxIndex] < 0.0f) for (float& v : q) v = -v;
+	uint32_t small[3]; int k = 0;
+	for (int i = 0; i < 4; i++) {
+		if (i == maxIndex) continue;
+		// (float + double) / double * float: evaluated in double, truncated
+		const double v = ((double)q[i] + (1.0 / std::sqrt(2.0))) / std::sqrt(2.0) * (double)1023.0f;
+		small[k++] = (v == v) ? (uint32_t)(int64_t)v : 0u;
+	}
+	return ((uint32_t)maxIndex << 30) | (small[0] << 20) | (small[1] << 10) | small[2];
+}
+
+struct Indexed {
+	std::vector<float> pos, nrm, uv, tan;
+	std::vector<uint32_t> tcomp, idx;
+};
+
+void index_mesh(const Soup& s, float tol, Indexed& m)
+{
+	std::vector<size_t> firstOf;
+	weld(s, tol, m.idx, firstOf);
+	const size_t V = firstOf.size();
+	m.pos.resize(V * 3); m.nrm.resize(V * 3); m.uv.resize(V * 2);
+	for (size_t v = 0; v < V; v++) {
+		const size_t f = firstOf[v];
+		for (int k = 0; k < 3; k++) { m.pos[v * 3 + k] = s.pos[f * 3 + k]; m.nrm[v * 3 + k] = s.nrm[f * 3 + k]; }
+		for (int k = 0; k < 2; k++) m.uv[v * 2 + k] = s.uv[f * 2 + k];
+	}
+	std::vector<double> P(m.pos.begin(), m.pos.end()), UV(m.uv.begin(), m.uv.end()), N(m.nrm.begin(), m.nrm.end()), t4;
+	tangent_space(m.idx, P, UV, N, t4);
+	m.tan.resize(V * 4);
+	for (size_t i = 0; i < V * 4; i++) m.tan[i] = (float)t4[i];
+	m.tcomp.resize(V);
+	for (size_t v = 0; v < V; v++) m.tcomp[v] = pack_tbn(&m.tan[v * 4], &m.nrm[v * 3]);
+}
+
+// ---------------------------------------------------------------------------
+// OBJ / MTL
+// ---------------------------------------------------------------------------
+struct Material {
+	std::string name;
+	std::string baseColor, roughness, metalness, alphaMask, normalMap, emissive;
+};
+struct MeshInfo { std::string name; size_t material, first, count; };
+struct Model {
+	std::vector<Material> materials;
+	std::vector<MeshInfo> meshes;
+	std::vector<float> pos, nrm, uv; // triangle soup
+};
+
+inline void trim(std::string_view& s)
+{
+	while (!s.empty() && (s.front() == ' ' || s.front() == '\t' || s.front() == '\r')) s.remove_prefix(1);
+	while (!s.empty() && (s.back() == ' ' || s.back() == '\t' || s.back() == '\r' || s.back() == '\n')) s.remove_suffix(1);
+}
+inline std::string_view next_token(std::string_view& s)
+{
+	trim(s);
+	size_t n = 0;
+	while (n < s.size() && s[n] != ' ' && s[n] != '\t') n++;
+	std::string_view t = s.substr(0, n);
+	s.remove_prefix(n);
+	return t;
+}
+inline bool parse_float(std::string_view t, float& out)
+{
+	if (!t.empty() && t.front() == '+') t.remove_prefix(1);
+	auto r = std::from_chars(t.data(), t.data() + t.size(), out);
+	return r.ec == std::errc() && r.ptr == t.data() + t.size();
+}
+inline bool parse_int(std::string_view t, long& out)
+{
+	auto r = std::from_chars(t.data(), t.data() + t.size(), out);
+	return r.ec == std::errc() && r.ptr == t.data() + t.size();
+}
+
+// the file name of a texture statement: options ("-bm 1.0", "-o u v w", ...) come first
+std::string texture_name(std::string_view rest)
+{
+	static const struct { const char* opt; int args; } kOpts[] = {
+		{ "-blendu", 1 }, { "-blendv", 1 }, { "-boost", 1 }, { "-mm", 2 }, { "-o", 3 }, { "-s", 3 }, { "-t", 3 },
+		{ "-texres", 1 }, { "-clamp", 1 }, { "-bm", 1 }, { "-imfchan", 1 }, { "-type", 1 } };
+	for (;;) {
+		trim(rest);
+		bool took = false;
+		for (auto& o : kOpts) {
+			const size_t n = std::strlen(o.opt);
+			if (rest.size() > n && rest.substr(0, n) == o.opt && (rest[n] == ' ' || rest[n] == '\t')) {
+				rest.remove_prefix(n);
+				for (int a = 0; a < o.args; a++) next_token(rest);
+				took = true;
+				break;
+			}
+		}
+		if (!took) break;
+	}
+	trim(rest);
+	return std::string(rest);
+}
+
+int load_mtl(const std::string& path, const std::string& prefix, std::vector<Material>& out)
+{
+	std::ifstream in(path);
+	if (!in) return fail("cannot open material library '%s'", path.c_str());
+	std::string line;
+	while (std::getline(in, line)) {
+		std::string_view s(line);
+		const std::string_view key = next_token(s);
+		if (key.empty() || key.front() == '#') continue;
+		if (key == "newmtl") { trim(s); out.push_back({}); out.back().name = std::string(s); continue; }
+		if (out.empty()) continue;
+		Material& m = out.back();
+		// load_model_obj.cpp:61-76: paths are prefixed with the OBJ's directory
+		auto set = [&](std::string& dst) { const std::string n = texture_name(s); if (!n.empty()) dst = prefix + n; };
+		if (key == "map_Kd") set(m.baseColor);
+		else if (key == "map_Pr") set(m.roughness);
+		else if (key == "map_Pm") set(m.metalness);
+		else if (key == "map_d") set(m.alphaMask);
+		else if (key == "norm") set(m.normalMap);
+		else if (key == "map_Ke") set(m.emissive);
+	}
+	return 0;
+}
+
+struct Corner { long v, vt, vn; };
+
+int load_obj(const char* path, Model& model)
+{
+	std::ifstream in(path);
+	if (!in) return fail("cannot open '%s'", path);
+	const char* slash = std::strrchr(path, '/');
+	const std::string prefix = slash ? std::string(path, slash + 1) : std::string();
+
+	std::vector<float> P, T, N;
+	struct Face { Corner c[3]; long mat; };
+	struct Shape { std::string name; std::vector<Face> faces; };
+	std::vector<Shape> shapes(1);
+	std::unordered_map<std::string, size_t> matIndex;
+	long curMat = -1;
+	bool haveLib = false;
+	std::string line;
+	size_t lineNo = 0;
+	while (std::getline(in, line)) {
+		lineNo++;
+		std::string_view s(line);
+		const std::string_view key = next_token(s);
+		if (key.empty() || key.front() == '#') continue;
+		if (key == "v" || key == "vn" || key == "vt") {
+			const int want = key == "vt" ? 2 : 3;
+			float f[3] = { 0, 0, 0 };
+			for (int k = 0; k < want; k++)
+				if (!parse_float(next_token(s), f[k])) return fail("%s:%zu: bad number", path, lineNo);
+			std::vector<float>& dst = key == "v" ? P : key == "vn" ? N : T;
+			dst.insert(dst.end(), f, f + want);
+		} else if (key == "g" || key == "o") {
+			trim(s);
+			shapes.push_back({});
+			shapes.back().name = std::string(s);
+		} else if (key == "mtllib") {
+			trim(s);
+			if (!haveLib) {
+				if (load_mtl(prefix + std::string(s), prefix, model.materials)) return 1;
+				for (size_t i = 0; i < model.materials.size(); i++) matIndex.emplace(model.materials[i].name, i);
+				haveLib = true;
+			}
+		} else if (key == "usemtl") {
+			trim(s);
+			auto it = matIndex.find(std::string(s));
+			if (it == matIndex.end()) return fail("%s:%zu: material '%.*s' not found", path, lineNo, (int)s.size(), s.data());
+			curMat = (long)it->second;
+		} else if (key == "f") {
+			std::vector<Corner> cs;
+			for (;;) {
+				std::string_view t = next_token(s);
+				if (t.empty()) break;
+				Corner c{ -1, -1, -1 };
+				long* dst[3] = { &c.v, &c.vt, &c.vn };
+				const long counts[3] = { (long)P.size() / 3, (long)T.size() / 2, (long)N.size() / 3 };
+				for (int k = 0; k < 3; k++) { // v, v/vt, v//vn, v/vt/vn; negative = relative to the elements read so far
+					size_t n = 0;
+					while (n < t.size() && t[n] != '/') n++;
+					if (n) {
+						long v;
+						if (!parse_int(t.substr(0, n), v) || v == 0) return fail("%s:%zu: bad face index", path, lineNo);
+						*dst[k] = v > 0 ? v - 1 : counts[k] + v;
+						if (*dst[k] < 0 || *dst[k] >= counts[k]) return fail("%s:%zu: face index out of range", path, lineNo);
+					}
+					if (n >= t.size()) break;
+					t.remove_prefix(n + 1);
+				}
+				if (c.v < 0) return fail("%s:%zu: face corner without a position", path, lineNo);
+				// the reference reads texcoords[idx*2] and normals[idx*3] unconditionally (load_model_obj.cpp:148-157)
+				if (c.vt < 0 || c.vn < 0) return fail("%s:%zu: face corner without texture coordinate or normal", path, lineNo);
+				cs.push_back(c);
+			}
+			if (cs.size() < 3) return fail("%s:%zu: face with fewer than three corners", path, lineNo);
+			if (curMat < 0) return fail("%s:%zu: face without a material", path, lineNo);
+			auto emit = [&](const Corner& a, const Corner& b, const Corner& c) { shapes.back().faces.push_back({ { a, b, c }, curMat }); };
+			if (cs.size() == 3) emit(cs[0], cs[1], cs[2]);
+			else if (cs.size() == 4) {
+				// rapidobj: split along the shorter diagonal (rapidobj.hpp:7365-7426)
+				auto d2 = [&](const Corner& a, const Corner& b) {
+					const float ex = P[a.v * 3 + 0] - P[b.v * 3 + 0], ey = P[a.v * 3 + 1] - P[b.v * 3 + 1], ez = P[a.v * 3 + 2] - P[b.v * 3 + 2];
+					return ex * ex + ey * ey + ez * ez;
+				};
+				const bool d02less = d2(cs[0], cs[2]) < d2(cs[1], cs[3]);
+				emit(cs[0], cs[1], d02less ? cs[2] : cs[3]);
+				emit(d02less ? cs[0] : cs[1], cs[2], cs[3]);
+			} else {
+				for (size_t k = 1; k + 1 < cs.size(); k++) emit(cs[0], cs[k], cs[k + 1]);
+			}
+		}
+	}
+	// load_model_obj.cpp:95-169: per shape, one mesh per material used in it
+	for (const Shape& sh : shapes) {
+		std::vector<long> active;
+		for (const auto& f : sh.faces)
+			if (std::find(active.begin(), active.end(), f.mat) == active.end()) active.push_back(f.mat);
+		for (long mat : active) {
+			MeshInfo mi;
+			mi.name = active.size() == 1 ? sh.name : sh.name + "::" + model.materials[mat].name;
+			mi.material = (size_t)mat;
+			mi.first = model.pos.size() / 3;
+			for (const auto& f : sh.faces) {
+				if (f.mat != mat) continue;
+				for (const Corner& c : f.c) {
+					model.pos.insert(model.pos.end(), &P[c.v * 3], &P[c.v * 3] + 3);
+					model.uv.insert(model.uv.end(), &T[c.vt * 2], &T[c.vt * 2] + 2);
+					model.nrm.insert(model.nrm.end(), &N[c.vn * 3], &N[c.vn * 3] + 3);
+				}
+			}
+			mi.count = model.pos.size() / 3 - mi.first;
+			model.meshes.push_back(std::move(mi));
+		}
+	}
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// textures and the file
+// ---------------------------------------------------------------------------
+struct TexEntry { std::string srcPath, newPath; uint8_t space, channels; };
+
+void write_u32(FILE* f, uint32_t v) { std::fwrite(&v, 4, 1, f); }
+void write_string(FILE* f, const std::string& s)
+{
+	write_u32(f, (uint32_t)s.size() + 1);
+	std::fwrite(s.c_str(), 1, s.size() + 1, f);
+}
+
+} // namespace
+
+extern "C" const char* vkr_bake_last_error(void) { return g_err; }
+
+extern "C" int vkr_index_mesh(const float* positions, const float* normals, const float* texcoords, uint32_t n, float tolerance,
+                              vkr_indexed_mesh* out)
+{
+	if (!positions || !normals || !texcoords || !out) return fail("vkr_index_mesh: NULL argument");
+	if (n % 3) return fail("vkr_index_mesh: %u soup vertices is not a whole number of triangles", n);
+	std::memset(out, 0, sizeof *out);
+	Indexed m;
+	index_mesh(Soup{ positions, normals, texcoords, n }, tolerance, m);
+	auto dup = [](const auto& v) {
+		using T = typename std::decay_t<decltype(v)>::value_type;
+		T* p = (T*)std::malloc(std::max<size_t>(1, v.size()) * sizeof(T));
+		if (p && !v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+		return p;
+	};
+	out->vertexCount = (uint32_t)m.tcomp.size(); out->indexCount = (uint32_t)m.idx.size();
+	out->positions = dup(m.pos); out->normals = dup(m.nrm); out->texcoords = dup(m.uv); out->tangents = dup(m.tan);
+	out->tangentsComp = dup(m.tcomp); out->indices = dup(m.idx);
+	if (!out->positions || !out->normals || !out->texcoords || !out->tangents || !out->tangentsComp || !out->indices) {
+		vkr_indexed_mesh_free(out);
+		return fail("vkr_index_mesh: out of memory");
+	}
+	return 0;
+}
+
+extern "C" void vkr_indexed_mesh_free(vkr_indexed_mesh* m)
+{
+	if (!m) return;
+	std::free(m->positions); std::free(m->normals); std::free(m->texcoords); std::free(m->tangents);
+	std::free(m->tangentsComp); std::free(m->indices);
+	std::memset(m, 0, sizeof *m);
+}
+
+extern "C" int vkr_bake_obj(const char* obj_path, const char* out_path, int copy_textures)
+{
+	namespace fs = std::filesystem;
+	if (!obj_path || !out_path) return fail("vkr_bake_obj: NULL path");
+	Model model;
+	if (load_obj(obj_path, model)) return 1;
+	// normalize_, main-bake/main.cpp:236-251
+	for (Material& m : model.materials) {
+		if (m.baseColor.empty()) m.baseColor = "assets-src/main/rgba1111.png";
+		if (m.roughness.empty()) m.roughness = "assets-src/main/r1.png";
+		if (m.metalness.empty()) m.metalness = "assets-src/main/r1.png";
+		if (m.emissive.empty()) m.emissive = "assets-src/main/rgb000.png";
+	}
+	// index_meshes_, main-bake/main.cpp:394-421 (tolerance 1e-5, main.cpp:75-78)
+	std::vector<Indexed> indexed(model.meshes.size());
+	for (size_t i = 0; i < model.meshes.size(); i++) {
+		const MeshInfo& mi = model.meshes[i];
+		index_mesh(Soup{ &model.pos[mi.first * 3], &model.nrm[mi.first * 3], &model.uv[mi.first * 2], mi.count }, 1e-5f, indexed[i]);
+	}
+	// find_unique_textures_ + new_paths_, main-bake/main.cpp:426-476: ids in order of first use
+	const fs::path outname(out_path);
+	const fs::path rootdir = outname.parent_path();
+	const fs::path texdir = outname.stem().string() + "-tex";
+	std::vector<TexEntry> textures;
+	std::unordered_map<std::string, uint32_t> texId;
+	auto add = [&](const std::string& p, uint8_t space, uint8_t channels) {
+		if (p.empty() || texId.count(p)) return;
+		texId.emplace(p, (uint32_t)textures.size());
+		textures.push_back({ p, (texdir / fs::path(p).filename()).string(), space, channels });
+	};
+	for (const Material& m : model.materials) {
+		add(m.baseColor, 1, 4); add(m.roughness, 0, 1); add(m.metalness, 0, 1);
+		add(m.alphaMask, 1, 4); add(m.normalMap, 0, 3); add(m.emissive, 1, 4);
+	}
+	std::error_code ec;
+	if (!rootdir.empty()) fs::create_directories(rootdir, ec);
+	fs::path mainpath = rootdir / outname.stem();
+	mainpath.replace_extension("comp5892mesh");
+	FILE* f = std::fopen(mainpath.string().c_str(), "wb");
+	if (!f) return fail("unable to open '%s' for writing", mainpath.string().c_str());
+	// write_model_data_, main-bake/main.cpp:276-389
+	static const char kMagic[16] = "\0\0COMP5892Mmesh";
+	char variant[16] = "21-tan";
+	std::fwrite(kMagic, 1, 16, f);
+	std::fwrite(variant, 1, 16, f);
+	write_u32(f, (uint32_t)textures.size());
+	for (const TexEntry& t : textures) {
+		write_string(f, t.newPath);
+		std::fwrite(&t.space, 1, 1, f);
+		std::fwrite(&t.channels, 1, 1, f);
+	}
+	write_u32(f, (uint32_t)model.materials.size());
+	for (const Material& m : model.materials)
+		for (const std::string* p : { &m.baseColor, &m.roughness, &m.metalness, &m.alphaMask, &m.normalMap, &m.emissive })
+			write_u32(f, p->empty() ? 0xffffffffu : texId.at(*p));
+	write_u32(f, (uint32_t)model.meshes.size());
+	for (size_t i = 0; i < model.meshes.size(); i++) {
+		const Indexed& m = indexed[i];
+		write_u32(f, (uint32_t)model.meshes[i].material);
+		write_u32(f, (uint32_t)m.tcomp.size());
+		write_u32(f, (uint32_t)m.idx.size());
+		std::fwrite(m.pos.data(), 4, m.pos.size(), f);
+		std::fwrite(m.nrm.data(), 4, m.nrm.size(), f);
+		std::fwrite(m.uv.data(), 4, m.uv.size(), f);
+		std::fwrite(m.tan.data(), 4, m.tan.size(), f);
+		std::fwrite(m.tcomp.data(), 4, m.tcomp.size(), f);
+		std::fwrite(m.idx.data(), 4, m.idx.size(), f);
+	}
+	const bool bad = std::ferror(f) != 0;
+	if (std::fclose(f) != 0 || bad) return fail("writing '%s' failed", mainpath.string().c_str());
+	if (copy_textures) {
+		fs::create_directories(rootdir / texdir, ec);
+		for (const TexEntry& t : textures) fs::copy_file(t.srcPath, rootdir / t.newPath, fs::copy_options::none, ec); // existing files are kept
+	}
+	return 0;
+}
