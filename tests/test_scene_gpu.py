@@ -73,6 +73,56 @@ def test_repacked_material_chains(ctx, micro):
     sc.close()
 
 
+def test_baked_obj_renders_like_the_oracle(ctx, tmp_path):
+    """OBJ + MTL -> libvkr_bake.so -> .comp5892mesh + copied textures -> vkr_scene_load -> frames equal to the
+    oracle's for the same file: the bake step feeds the renderer without the reference's tools."""
+    import shutil
+    from oracle import oracle
+    from vulkanrenderer_amd import abi, bake, baked_model, renderer
+    src = tmp_path / "src"
+    (src / "tex").mkdir(parents=True)
+    (src / "assets-src" / "main").mkdir(parents=True)
+    for f in ("model.obj", "model.mtl"):
+        shutil.copy(os.path.join(GOLD, "bake", f), str(src / f))
+    # the renderer, like the reference's descriptor-set code (main/main.cpp:770-846), needs a normal map per material
+    with open(str(src / "model.mtl"), "a") as f:
+        f.write("\tnorm tex/a_Normal.png\n")
+    rng = np.random.default_rng(21)
+
+    def png(path, size, alpha=None):
+        a = rng.integers(0, 256, (size, size, 4), dtype=np.uint8)
+        a[..., 3] = 255 if alpha is None else alpha
+        renderer.write_png(str(path), a)
+    for name in ("a_BaseColor", "r-a_Specular", "m-a_Specular", "a_Normal", "a_Emissive", "leaf_Normal"):
+        png(src / "tex" / (name + ".png"), 16)
+    yy, xx = np.mgrid[0:16, 0:16]
+    png(src / "tex" / "leaf_BaseColor.png", 16, alpha=np.where((xx // 4 + yy // 4) % 2, 255, 20).astype(np.uint8))
+    for name in ("r1", "rgb000", "rgba1111"):   # the bake tool's fallback textures (main-bake/main.cpp:44-46)
+        png(src / "assets-src" / "main" / (name + ".png"), 2)
+    cwd = os.getcwd()
+    os.chdir(str(src))   # texture paths in the MTL and the fallbacks are relative to the working directory
+    try:
+        bake.bake_obj("model.obj", str(tmp_path / "out" / "model.comp5892mesh"), copy_textures=True)
+    finally:
+        os.chdir(cwd)
+    path = str(tmp_path / "out" / "model.comp5892mesh")
+    assert sorted(os.listdir(str(tmp_path / "out" / "model-tex")))[0] == "a_BaseColor.png" and len(os.listdir(str(tmp_path / "out" / "model-tex"))) == 10
+    sc = renderer.Scene(ctx, path=path)
+    ps = abi.PackedScene(*baked_model.load_scene_arrays(path, image_loader=renderer.decode_png))
+    osc = oracle.OracleScene(ps)
+    assert sc.stats()["triangles"] == ps.triangle_count == 49
+    W, H = 160, 90
+    pose = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 3.2, 0.6, 2.4, 1]
+    for kw in (dict(deferred=True), dict(), dict(debug=2)):
+        p = abi.make_params(W, H, renderer.make_uniforms(W, H, pose, kw.get("debug", 1)), shadow_size=256, **kw)
+        ref, got = osc.render(p), sc.render(p)
+        assert (ref["tri_id"] != 0xFFFFFFFF).mean() > 0.1
+        for k in ("tri_id", "depth_bits", "mip_level"):
+            assert np.array_equal(ref[k], got[k]), k
+        assert np.abs(ref["rgba8"].astype(np.int32) - got["rgba8"].astype(np.int32)).max() <= 1
+    sc.close()
+
+
 def test_mip_chain_odd_sizes(ctx):
     from oracle import oracle
     from vulkanrenderer_amd import abi, renderer
