@@ -55,6 +55,12 @@ def _worker(rank, world, port, full):
                 assert np.array_equal(out.numpy(), img.astype(np.uint8))
             else:
                 assert out is None
+        # every rank gets the frame
+        comp = BandCompositor(W, H, "cpu", everywhere=True)
+        x0, y0, x1, y1 = comp.rect
+        comp.local.zero_()
+        comp.local[: y1 - y0] = torch.from_numpy(full[y0:y1].astype(np.uint8))
+        assert np.array_equal(comp.gather().numpy(), full.astype(np.uint8))
         # timing convention of bench.py: max over ranks
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -31,10 +31,12 @@ def pose_indices(rank, world, n_poses):
 class BandCompositor:
     """Gathers the per-rank RGBA8 bands of one frame into the full image on rank 0."""
 
-    def __init__(self, width, height, device, rank=None, world=None, host_collective=False):
+    def __init__(self, width, height, device, rank=None, world=None, host_collective=False, everywhere=False):
         """host_collective: gather through host tensors (gloo rehearsals); the product path gathers device
-        tensors over RCCL."""
+        tensors over RCCL.  everywhere: every rank ends up with the full frame (one all-gather instead of the
+        gather to rank 0), for hosts where each GPU drives a display of its own."""
         self.host = host_collective
+        self.everywhere = everywhere
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
         self.width, self.height = width, height
@@ -45,18 +47,22 @@ class BandCompositor:
         self.local = torch.zeros((self.band_h, width, 4), dtype=torch.uint8, device=device)
         gdev = "cpu" if host_collective else device
         self.gathered = ([torch.empty(self.local.shape, dtype=torch.uint8, device=gdev) for _ in range(self.world)]
-                         if self.rank == 0 else None)
+                         if (self.rank == 0 or everywhere) else None)
 
     @property
     def rect(self):
         return self.rects[self.rank]
 
     def gather(self):
-        """Returns the H x W x 4 frame on rank 0, None elsewhere."""
+        """Returns the H x W x 4 frame on rank 0 (on every rank with `everywhere`), None elsewhere."""
         if self.world == 1:
             return self.local[: self.height]
-        dist.gather(self.local.cpu() if self.host else self.local, self.gathered, dst=0)
-        if self.rank != 0:
-            return None
+        src = self.local.cpu() if self.host else self.local
+        if self.everywhere:
+            dist.all_gather(self.gathered, src)
+        else:
+            dist.gather(src, self.gathered, dst=0)
+            if self.rank != 0:
+                return None
         rows = [g[: r[3] - r[1]] for g, r in zip(self.gathered, self.rects) if r[3] > r[1]]
         return torch.cat(rows, dim=0)
