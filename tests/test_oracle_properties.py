@@ -3,6 +3,8 @@ pieces of Vulkan fixed-function behaviour it restates, and the mode dispatch of
 record_commands (main/main.cpp:3836-4195)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -308,3 +310,20 @@ def test_banded_oracle_equals_whole_frame(micro, micro_oracle):
         b = micro_oracle.render(p, threads=4)
         for k in a:
             assert np.array_equal(a[k], b[k]), (kw, k)
+
+
+def test_oracle_reproduces_committed_frames(micro_oracle):
+    """tests/golden/micro_frames.npz (tests/make_golden_frames.py): every mode, two poses, 64x36.  Integer buffers
+    must be identical; colour may move by one step where the host's libm rounds a transcendental differently."""
+    import make_golden_frames as g
+    from oracle import oracle
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "micro_frames.npz"))
+    got = g.render_all(micro_oracle, oracle.make_uniforms)
+    assert set(gold.files) == set(got)
+    for k in gold.files:
+        if k.endswith("rgba8"):
+            assert np.abs(gold[k].astype(np.int32) - got[k].astype(np.int32)).max() <= 1, k
+        else:
+            assert np.array_equal(gold[k], got[k]), k
+    # the frames are not trivially empty
+    assert (gold["deferred/start/tri_id"] != 0xFFFFFFFF).mean() > 0.3 and gold["overdraw/p1/stencil"].max() >= 2

@@ -71,6 +71,24 @@ def test_micro_scene_modes(gpu, micro_oracle, mode, pose):
     compare(ref, got, mode)
 
 
+def test_committed_golden_frames(gpu):
+    """The HIP path against tests/golden/micro_frames.npz (oracle output committed with the script that made it,
+    tests/make_golden_frames.py): every mode, two poses; integer buffers bit-exact, colour within 1/255."""
+    import os
+    import make_golden_frames as g
+    from vulkanrenderer_amd import renderer
+    ctx, sc = gpu
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "micro_frames.npz"))
+    got = g.render_all(sc, renderer.make_uniforms)
+    assert set(gold.files) == set(got) and len(gold.files) == 9 * 2 * 5
+    for k in gold.files:
+        if k.endswith("rgba8"):
+            d = np.abs(gold[k].astype(np.int32) - got[k].astype(np.int32))
+            assert d.max() <= 1, "%s: colour differs by %d/255" % (k, int(d.max()))
+        else:
+            assert np.array_equal(gold[k], got[k]), "%s differs at %d pixels" % (k, int((gold[k] != got[k]).sum()))
+
+
 def test_odd_texture_sizes():
     """Non-power-of-two textures whose sizes differ inside a material: the general REPEAT wrap and the
     per-texture footprint rebuild, against the oracle."""
