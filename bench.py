@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--partition", default="poses", choices=["poses", "sortfirst"])
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--tex-size", type=int, default=1024)
+    ap.add_argument("--shadow", type=int, default=0,
+                    help="deferred mode: also render an N x N light depth map per frame (the 'deferred + shadow map' stress composition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs, collectives on host tensors)")
@@ -130,6 +132,8 @@ def main():
     from vulkanrenderer_amd.dist import BandCompositor
 
     kw = dict(deferred=(args.mode == "deferred"), mosaic=(args.mode == "mosaic"), debug=1)
+    if args.shadow and args.mode == "deferred":
+        kw.update(shadow_size=args.shadow, flags=abi.FRAME_SHADOW_PASS)
     sortfirst = args.partition == "sortfirst" and world > 1
     comp = None
     if sortfirst:
@@ -231,7 +235,8 @@ def main():
             "scaling": "strong" if sortfirst else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "frames_per_s": round(frames_total / elapsed, 2),
-            "config": {"workload": "SunTemple-proxy v1 %s shading, 21 brazier lights, %dx%d, fly-through poses, whole frame" % (args.mode, W, H),
+            "config": {"workload": "SunTemple-proxy v1 %s shading, 21 brazier lights, %dx%d, fly-through poses, whole frame%s" % (
+                args.mode, W, H, (" + %dx%d light depth map" % (args.shadow, args.shadow)) if (args.shadow and args.mode == "deferred") else ""),
                        "triangles": stats["triangles"], "vertices": stats["vertices"], "texture_bytes": stats["texture_bytes"],
                        "partition": args.partition, "scene_setup_s": round(t_scene, 1)},
             "roofline": roofline, "cpu_baseline": cpu,

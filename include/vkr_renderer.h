@@ -131,6 +131,10 @@ typedef struct vkr_uniforms { /* struct Uniforms, main/main.cpp:234-240 */
 
 /* flags for vkr_frame_params::flags */
 #define VKR_FRAME_DEFAULT 0u
+/* deferred mode only: also render the light's depth map (shadow_size^2) and hand it out through
+ * vkr_frame_out::shadow_map.  The reference's deferred path has no shadow pass (main/main.cpp:3836-3946); this is
+ * the "deferred + shadow map" stress composition, the map is not sampled by the lighting. */
+#define VKR_FRAME_SHADOW_PASS 1u
 
 typedef struct vkr_frame_params {
 	uint32_t width, height; /* VkExtent2D aExtent, main/main.cpp:3714 */

@@ -89,6 +89,21 @@ def test_committed_golden_frames(gpu):
             assert np.array_equal(gold[k], got[k]), "%s differs at %d pixels" % (k, int((gold[k] != got[k]).sum()))
 
 
+def test_deferred_with_shadow_pass_flag(gpu, micro_oracle):
+    """VKR_FRAME_SHADOW_PASS: the deferred frame is unchanged and the light's depth map equals the forward path's
+    (and the oracle's)."""
+    from vulkanrenderer_amd import abi, renderer
+    ctx, sc = gpu
+    W, H = 96, 54
+    u = renderer.make_uniforms(W, H, POSES["p1"], 1)
+    plain = sc.render(abi.make_params(W, H, u, deferred=True, shadow_size=256))
+    both = sc.render(abi.make_params(W, H, u, deferred=True, shadow_size=256, flags=abi.FRAME_SHADOW_PASS))
+    fwd = micro_oracle.render(abi.make_params(W, H, u, shadow_size=256))
+    for k in ("rgba8", "tri_id", "depth_bits", "gbuf_normal", "gbuf_albedo"):
+        assert np.array_equal(plain[k], both[k]), k
+    assert np.array_equal(both["shadow_map"], fwd["shadow_map"]) and both["shadow_map"].shape == (256, 256)
+
+
 def test_odd_texture_sizes():
     """Non-power-of-two textures whose sizes differ inside a material: the general REPEAT wrap and the
     per-texture footprint rebuild, against the oracle."""

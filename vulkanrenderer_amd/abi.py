@@ -160,8 +160,12 @@ class PackedScene:
         return sum(len(m["indices"]) // 3 for m in self.meshes)
 
 
-def make_params(width, height, uniforms, debug=1, mosaic=False, deferred=False, shadow_size=0, rect=None):
+FRAME_SHADOW_PASS = 1  # VKR_FRAME_SHADOW_PASS
+
+
+def make_params(width, height, uniforms, debug=1, mosaic=False, deferred=False, shadow_size=0, rect=None, flags=0):
     p = FrameParams()
+    p.flags = flags
     p.width, p.height, p.shadow_size = width, height, shadow_size
     p.debugVisualisation, p.mosaicEffect, p.deferredShading = int(debug), int(bool(mosaic)), int(bool(deferred))
     if rect is not None:

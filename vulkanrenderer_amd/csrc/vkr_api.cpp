@@ -855,26 +855,34 @@ static void cam_mat(const float m[16], Mat4& M) { memcpy(M.m, m, sizeof(float) *
 
 // shadow pass (main/main.cpp:3950-3984) + regular pass (main/main.cpp:3987-4077)
 // over `view`; colour lands in `colourDst` (view-rectangle sized)
+// Depth-only pass from the light (shadowOffscreen.vert:9-11; main/main.cpp:3086-3137, 3950-3984): opaque meshes,
+// no culling, slope-scaled bias; leaves the map in c->shadow.
+static int run_shadow(vkr_context* c, const vkr_scene* s, const vkr_frame_params& fp, uint32_t statusSlot)
+{
+	const uint32_t S = fp.shadow_size ? fp.shadow_size : 2048;
+	int rc;
+	if ((rc = c->shadow.ensure((size_t)S * S * 4))) return rc;
+	GeomPass g;
+	cam_mat(fp.uniforms.depthMVPUniform.depthMVP, g.M);
+	g.view = make_view(S, S, 0, 0, S, S);
+	g.first = 0; g.count = s->dev.nTriOpaque; // opaque meshes only
+	g.cullOpaque = 0; g.cullAlpha = 0; g.useOrderB = 0; g.alphaTest = 0; g.shadow = 1; g.keys = false;
+	if ((rc = run_geometry(c, s, g, statusSlot))) return rc;
+	StageTimer t(c, ST_RASTER_SHADOW);
+	RasterArgs r;
+	fill_raster_args(c, s, g.view, r);
+	r.depthOut = c->shadow.as<float>();
+	vkr_launch_raster(c->stream, RASTER_SHADOW, r);
+	return VKR_OK;
+}
+
 static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_params& fp, const ViewDev& view, uint32_t* colourDst,
                        uint32_t statusSlot, const vkr_frame_out* out, bool writeSide)
 {
 	const vkr_uniforms& u = fp.uniforms;
 	const uint32_t S = fp.shadow_size ? fp.shadow_size : 2048;
 	int rc;
-	if ((rc = c->shadow.ensure((size_t)S * S * 4))) return rc;
-	{
-		GeomPass g;
-		cam_mat(u.depthMVPUniform.depthMVP, g.M);
-		g.view = make_view(S, S, 0, 0, S, S);
-		g.first = 0; g.count = s->dev.nTriOpaque; // opaque meshes only
-		g.cullOpaque = 0; g.cullAlpha = 0; g.useOrderB = 0; g.alphaTest = 0; g.shadow = 1; g.keys = false;
-		if ((rc = run_geometry(c, s, g, statusSlot))) return rc;
-		StageTimer t(c, ST_RASTER_SHADOW);
-		RasterArgs r;
-		fill_raster_args(c, s, g.view, r);
-		r.depthOut = c->shadow.as<float>();
-		vkr_launch_raster(c->stream, RASTER_SHADOW, r);
-	}
+	if ((rc = run_shadow(c, s, fp, statusSlot))) return rc;
 	const size_t n = (size_t)(view.x1 - view.x0) * (view.y1 - view.y0);
 	if ((rc = c->vis.ensure(n * 8))) return rc;
 	if ((rc = c->depth.ensure(n * 4))) return rc;
@@ -956,8 +964,14 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 		cam_mat(u.sceneUniforms.projCam, g.M);
 		g.view = view; g.first = 0; g.count = s->dev.nTri;
 		g.cullOpaque = 1; g.cullAlpha = 0; g.useOrderB = 0; g.alphaTest = 1; g.shadow = 0; g.keys = false;
-		if ((rc = run_geometry(c, s, g, statusSlot))) return rc;
 		*nPasses = 1;
+		if (fp.flags & VKR_FRAME_SHADOW_PASS) {
+			// not a reference combination (its deferred path has no shadow pass): the map is rendered, handed out
+			// if asked for, and not sampled
+			if ((rc = run_shadow(c, s, fp, statusSlot + 1))) return rc;
+			*nPasses = 2;
+		}
+		if ((rc = run_geometry(c, s, g, statusSlot))) return rc;
 		{
 			StageTimer t(c, ST_RASTER_VIS);
 			RasterArgs r;
@@ -998,6 +1012,7 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 		if ((rc = copy_out(c, rgbaCopy, c->colour.p, n * 4)) || (rc = copy_out(c, out.tri_id, c->triId.p, n * 4)) ||
 		    (rc = copy_out(c, out.depth_bits, c->depth.p, n * 4)) || (rc = copy_out(c, out.gbuf_normal, c->gN.p, n * 8)) ||
 		    (rc = copy_out(c, out.gbuf_albedo, c->gA.p, n * 8))) return rc;
+		if ((fp.flags & VKR_FRAME_SHADOW_PASS) && (rc = copy_out(c, out.shadow_map, c->shadow.p, (size_t)S * S * 4))) return rc;
 	} else if (!fp.mosaicEffect && dbg == 1) {
 		// ---- forward + shadow map (main/main.cpp:3948-4079)
 		if ((rc = run_forward(c, s, fp, view, colourDst, statusSlot, &out, true))) return rc;
