@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 import numpy as np
 
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E peak
+FUSED_BYTES_PER_PIXEL = 12   # k_resolve_light: 8 (visibility buffer) read + 4 (RGBA8) written; texels and per-triangle data excluded
 LIGHT_BYTES_PER_PIXEL = 24   # 8 (normal+metal RGBA16F) + 8 (albedo+rough RGBA16F) + 4 (D32) read + 4 (RGBA8) written
 
 
@@ -92,6 +93,9 @@ def main():
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--shadow", type=int, default=0,
                     help="deferred mode: also render an N x N light depth map per frame (the 'deferred + shadow map' stress composition)")
+    ap.add_argument("--fused", action="store_true",
+                    help="deferred mode: G-buffer resolve and lighting as one kernel (VKR_FRAME_FUSED_LIGHTING); the roofline "
+                         "object then describes k_resolve_light with 12 B/pixel (8 read from the visibility buffer, 4 written)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs, collectives on host tensors)")
@@ -134,6 +138,8 @@ def main():
     kw = dict(deferred=(args.mode == "deferred"), mosaic=(args.mode == "mosaic"), debug=1)
     if args.shadow and args.mode == "deferred":
         kw.update(shadow_size=args.shadow, flags=abi.FRAME_SHADOW_PASS)
+    if args.fused and args.mode == "deferred":
+        kw["flags"] = kw.get("flags", 0) | abi.FRAME_FUSED_LIGHTING
     sortfirst = args.partition == "sortfirst" and world > 1
     comp = None
     if sortfirst:
@@ -188,6 +194,15 @@ def main():
     value = pixels_total / elapsed / 1e6
 
     roofline = None
+    fusedk = report.get("k_resolve_light")
+    if fusedk and fusedk[1]:
+        avg_ms = fusedk[0] / fusedk[1]
+        nbytes = FUSED_BYTES_PER_PIXEL * W * rh
+        achieved = nbytes / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "k_resolve_light",
+                    "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": nbytes,
+                    "note": "fused G-buffer resolve + lighting: replaces k_resolve_gbuf + k_deferred_light (44 B/pixel between them)"}
     light = report.get("k_deferred_light")
     if light and light[1]:
         avg_ms = light[0] / light[1]

@@ -135,6 +135,11 @@ typedef struct vkr_uniforms { /* struct Uniforms, main/main.cpp:234-240 */
  * vkr_frame_out::shadow_map.  The reference's deferred path has no shadow pass (main/main.cpp:3836-3946); this is
  * the "deferred + shadow map" stress composition, the map is not sampled by the lighting. */
 #define VKR_FRAME_SHADOW_PASS 1u
+/* deferred mode only: G-buffer resolve and lighting run as one kernel; the G-buffer stays in registers
+ * (rounded to half precision as the RGBA16F attachments round it) and is written out only if
+ * vkr_frame_out asks for it.  Same image, fewer microseconds; the two subpasses of the reference
+ * (main/main.cpp:3836-3946) are no longer separately visible to a profiler. */
+#define VKR_FRAME_FUSED_LIGHTING 2u
 
 typedef struct vkr_frame_params {
 	uint32_t width, height; /* VkExtent2D aExtent, main/main.cpp:3714 */

@@ -104,6 +104,25 @@ def test_deferred_with_shadow_pass_flag(gpu, micro_oracle):
     assert np.array_equal(both["shadow_map"], fwd["shadow_map"]) and both["shadow_map"].shape == (256, 256)
 
 
+@pytest.mark.parametrize("pose", list(POSES))
+def test_fused_lighting_equals_two_kernels(gpu, micro_oracle, pose):
+    """VKR_FRAME_FUSED_LIGHTING: same image and side buffers as the resolve + lighting pair, and within the
+    usual bounds of the oracle."""
+    from vulkanrenderer_amd import abi, renderer
+    ctx, sc = gpu
+    W, H = 160, 90
+    u = renderer.make_uniforms(W, H, POSES[pose], 1)
+    two = sc.render(abi.make_params(W, H, u, deferred=True))
+    one = sc.render(abi.make_params(W, H, u, deferred=True, flags=abi.FRAME_FUSED_LIGHTING))
+    for k in ("tri_id", "depth_bits", "gbuf_normal", "gbuf_albedo"):
+        assert np.array_equal(two[k], one[k]), k
+    assert np.abs(two["rgba8"].astype(np.int32) - one["rgba8"].astype(np.int32)).max() <= 1
+    compare(micro_oracle.render(abi.make_params(W, H, u, deferred=True)), one, "deferred")
+    # colour only: nothing but the image is written
+    img = sc.render(abi.make_params(W, H, u, deferred=True, flags=abi.FRAME_FUSED_LIGHTING), want=("rgba8",))["rgba8"]
+    assert np.array_equal(img, one["rgba8"])
+
+
 def test_odd_texture_sizes():
     """Non-power-of-two textures whose sizes differ inside a material: the general REPEAT wrap and the
     per-texture footprint rebuild, against the oracle."""

@@ -13,11 +13,12 @@ ap.add_argument("--no-foliage", action="store_true")
 ap.add_argument("--mode", default="deferred")
 ap.add_argument("--poses", default="0,64,128,256,400,511")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--fused", action="store_true", help="deferred: resolve and lighting in one kernel")
 a = ap.parse_args()
 packed = scenes.proxy_scene(tex_size=a.tex_size, foliage=not a.no_foliage)
 ctx = renderer.Context(0); sc = renderer.Scene(ctx, packed)
 W, H = a.width, a.height
-kw = dict(deferred=a.mode == "deferred", mosaic=a.mode == "mosaic", debug={"deferred": 1, "forward": 1, "mosaic": 1}.get(a.mode, 1) if not a.mode.isdigit() else int(a.mode))
+kw = dict(flags=abi.FRAME_FUSED_LIGHTING if a.fused else 0, deferred=a.mode == "deferred", mosaic=a.mode == "mosaic", debug={"deferred": 1, "forward": 1, "mosaic": 1}.get(a.mode, 1) if not a.mode.isdigit() else int(a.mode))
 fo = abi.FrameOut()  # no outputs requested: frames stay in the context's device buffers
 for pi in [int(x) for x in a.poses.split(",")]:
     u = renderer.make_uniforms(W, H, fly_pose(pi), kw["debug"])

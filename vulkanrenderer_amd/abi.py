@@ -161,6 +161,7 @@ class PackedScene:
 
 
 FRAME_SHADOW_PASS = 1  # VKR_FRAME_SHADOW_PASS
+FRAME_FUSED_LIGHTING = 2  # VKR_FRAME_FUSED_LIGHTING
 
 
 def make_params(width, height, uniforms, debug=1, mosaic=False, deferred=False, shadow_size=0, rect=None, flags=0):

@@ -11,6 +11,7 @@
 // the triangle's own planes (helper-invocation semantics).
 // Compiled with -ffp-contract=off (the mip-level buffer is an integer output).
 #include "vkr_kernels.h"
+#include "vkr_light.h"
 
 struct Frag {
 	uint32_t prim;   // submission-order index
@@ -315,6 +316,49 @@ __global__ __launch_bounds__(256) void k_resolve_debug(ResolveArgs a)
 	if (a.mip) a.mip[p] = mip;
 }
 
+// ---------------------------------------------------------------------------
+// G-buffer resolve and deferred lighting in one kernel (an option of the deferred path): the pixel's G-buffer
+// texels go from the resolve to the lighting in registers, rounded to half precision exactly as the RGBA16F
+// attachments round them, so the image is the one the two-kernel path produces.  The resolve keeps the
+// texture-address units busy and the lighting the vector ALU; in one kernel the wavefronts of a CU are in
+// different phases and the two overlap.  The attachments are written only if the caller asked for them.
+// A wavefront shades an 8x8 block (what the lighting's N.L skip wants).
+template <bool SAMECOL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_resolve_light(ResolveArgs a, LightArgs l)
+{
+	__shared__ float sDec[256];
+	__shared__ float sT[257];
+	sDec[threadIdx.x] = a.sc.srgbDecode[threadIdx.x];
+	vkr_load_srgb_table(sT, l.srgbThresh);
+	__syncthreads();
+	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	const uint32_t x = blockIdx.x * 16u + (wv & 1u) * 8u + (lane & 7u), y = blockIdx.y * 16u + (wv >> 1) * 8u + (lane >> 3);
+	if (x >= rw || y >= rh) return;
+	const size_t p = (size_t)y * rw + x;
+	const int px = (int)(a.view.x0 + x), py = (int)(a.view.y0 + y);
+	float depth; uint32_t prim;
+	decode_key(a.vis[p], depth, prim);
+	if (a.depth) a.depth[p] = depth;
+	if (a.triId) a.triId[p] = prim;
+	uint2 gn = make_uint2(0x2E662E66u, 0x2E662E66u), ga = gn; // attachment clears 0.1
+	Frag f;
+	if (prim != VKR_NO_PRIM && load_frag<false>(a, px, py, prim, f)) {
+		MatSample ms;
+		float N[3];
+		sample_material(a, f, sDec, ms);
+		shading_normal(a, f, ms.nm, N);
+		gn.x = vkr_f2h_hw(N[0]) | (vkr_f2h_hw(N[1]) << 16);
+		gn.y = vkr_f2h_hw(N[2]) | (vkr_f2h_hw(ms.metal) << 16);
+		ga.x = vkr_f2h_hw(ms.alb[0]) | (vkr_f2h_hw(ms.alb[1]) << 16);
+		ga.y = vkr_f2h_hw(ms.alb[2]) | (vkr_f2h_hw(ms.rough) << 16);
+	}
+	if (a.gN) a.gN[p] = gn;
+	if (a.gA) a.gA[p] = ga;
+	// deferredShading.frag discards where depth == 1: the clear colour stays
+	a.colour[p] = (depth == 1.0f) ? l.clearColour : vkr_light_pixel<SAMECOL>(l, sT, depth, gn, ga, x, y);
+}
+
 static dim3 grid16(const ViewDev& v) { return dim3((v.x1 - v.x0 + 15) / 16, (v.y1 - v.y0 + 15) / 16); }
 
 void vkr_launch_resolve_gbuf(hipStream_t s, const ResolveArgs& a)
@@ -328,4 +372,9 @@ void vkr_launch_resolve_forward(hipStream_t s, const ResolveArgs& a)
 void vkr_launch_resolve_debug(hipStream_t s, const ResolveArgs& a)
 {
 	hipLaunchKernelGGL(k_resolve_debug, grid16(a.view), dim3(256), 0, s, a);
+}
+void vkr_launch_resolve_light(hipStream_t s, const ResolveArgs& a, const LightArgs& l)
+{
+	if (vkr_lights_share_colour(l)) hipLaunchKernelGGL((k_resolve_light<true>), grid16(a.view), dim3(256), 0, s, a, l);
+	else hipLaunchKernelGGL((k_resolve_light<false>), grid16(a.view), dim3(256), 0, s, a, l);
 }

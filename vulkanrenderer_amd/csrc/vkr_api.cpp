@@ -52,12 +52,12 @@ int vkr_set_error_ext(int code, const char* fmt, ...)
 enum Stage {
 	ST_XFORM, ST_SETUP, ST_BIN_SCAN, ST_BIN_FILL, ST_RASTER_VIS, ST_RASTER_SHADOW, ST_RASTER_COUNT, ST_SORT_BINS,
 	ST_OVERSHADE, ST_RESOLVE_GBUF, ST_RESOLVE_FORWARD, ST_RESOLVE_DEBUG, ST_DEFERRED_LIGHT, ST_OVERVIS_COLOUR, ST_MOSAIC,
-	ST_COPY_OUT, ST_COUNT
+	ST_COPY_OUT, ST_RESOLVE_LIGHT, ST_COUNT
 };
 static const char* kStageNames[ST_COUNT] = {
 	"k_xform", "k_setup", "k_scan_tiles", "k_bin_fill", "k_raster_vis", "k_raster_shadow", "k_raster_count", "sort_bins",
 	"k_overshade", "k_resolve_gbuf", "k_resolve_forward", "k_resolve_debug", "k_deferred_light", "k_overvis_colour",
-	"k_mosaic", "copy_out"
+	"k_mosaic", "copy_out", "k_resolve_light"
 };
 
 struct DevBuf {
@@ -417,7 +417,7 @@ static hipEvent_t get_event(vkr_context* c)
 
 struct StageTimer {
 	vkr_context* c; Timed t; bool on;
-	StageTimer(vkr_context* ctx, int stage) : c(ctx), on(ctx->profiling == 1 || (ctx->profiling == 2 && stage == ST_DEFERRED_LIGHT))
+	StageTimer(vkr_context* ctx, int stage) : c(ctx), on(ctx->profiling == 1 || (ctx->profiling == 2 && (stage == ST_DEFERRED_LIGHT || stage == ST_RESOLVE_LIGHT)))
 	{
 		if (!on) return;
 		t.stage = stage; t.a = get_event(c); t.b = get_event(c);
@@ -980,32 +980,41 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 			r.alphaPass = s->anyAlphaTest ? 1 : 0;
 			vkr_launch_raster(c->stream, RASTER_VIS, r);
 		}
-		{
-			StageTimer t(c, ST_RESOLVE_GBUF);
-			ResolveArgs a;
-			memset(&a, 0, sizeof a);
-			a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.planes = c->planes.as<TriPlanes>(); a.vis = c->vis.as<unsigned long long>();
-			a.gN = c->gN.as<uint2>(); a.gA = c->gA.as<uint2>(); a.depth = c->depth.as<float>(); a.triId = c->triId.as<uint32_t>();
-			vkr_launch_resolve_gbuf(c->stream, a);
+		ResolveArgs a;
+		memset(&a, 0, sizeof a);
+		a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.planes = c->planes.as<TriPlanes>(); a.vis = c->vis.as<unsigned long long>();
+		a.gN = c->gN.as<uint2>(); a.gA = c->gA.as<uint2>(); a.depth = c->depth.as<float>(); a.triId = c->triId.as<uint32_t>();
+		LightArgs l;
+		memset(&l, 0, sizeof l);
+		l.view = view; l.gN = c->gN.as<uint2>(); l.gA = c->gA.as<uint2>(); l.depth = c->depth.as<float>();
+		l.colour = colourDst; l.srgbThresh = c->dThresh;
+		float invCam[16], invProj[16];
+		mat4_inverse(u.sceneUniforms.camera, invCam);
+		mat4_inverse(u.sceneUniforms.projection, invProj);
+		mat4_mul(invCam, invProj, l.invPC.m); // deferredShading.frag:36
+		memcpy(l.camPos, u.sceneUniforms.camPos, 16);
+		for (int i = 0; i < VKR_NUM_LIGHTS; i++) {
+			memcpy(l.lightPos[i], u.multipleLightsUniform.light[i].lightPos, 16);
+			memcpy(l.lightCol[i], u.multipleLightsUniform.light[i].lightColour, 16);
 		}
-		{
-			StageTimer t(c, ST_DEFERRED_LIGHT);
-			LightArgs l;
-			memset(&l, 0, sizeof l);
-			l.view = view; l.gN = c->gN.as<uint2>(); l.gA = c->gA.as<uint2>(); l.depth = c->depth.as<float>();
-			l.colour = colourDst; l.srgbThresh = c->dThresh;
-			float invCam[16], invProj[16];
-			mat4_inverse(u.sceneUniforms.camera, invCam);
-			mat4_inverse(u.sceneUniforms.projection, invProj);
-			mat4_mul(invCam, invProj, l.invPC.m); // deferredShading.frag:36
-			memcpy(l.camPos, u.sceneUniforms.camPos, 16);
-			for (int i = 0; i < VKR_NUM_LIGHTS; i++) {
-				memcpy(l.lightPos[i], u.multipleLightsUniform.light[i].lightPos, 16);
-				memcpy(l.lightCol[i], u.multipleLightsUniform.light[i].lightColour, 16);
+		// clear (0.1,0.1,0.1,0.1), main/main.cpp:3838-3841
+		const uint32_t c01 = host_srgb_encode(c->hThresh, 0.1f);
+		l.clearColour = c01 | (c01 << 8) | (c01 << 16) | ((uint32_t)floorf(0.1f * 255.0f + 0.5f) << 24);
+		if (fp.flags & VKR_FRAME_FUSED_LIGHTING) {
+			// one kernel; the attachments and the integer buffers are written only when the caller wants them
+			StageTimer t(c, ST_RESOLVE_LIGHT);
+			if (!out.gbuf_normal) a.gN = nullptr;
+			if (!out.gbuf_albedo) a.gA = nullptr;
+			if (!out.depth_bits) a.depth = nullptr;
+			if (!out.tri_id) a.triId = nullptr;
+			a.colour = colourDst;
+			vkr_launch_resolve_light(c->stream, a, l);
+		} else {
+			{
+				StageTimer t(c, ST_RESOLVE_GBUF);
+				vkr_launch_resolve_gbuf(c->stream, a);
 			}
-			// clear (0.1,0.1,0.1,0.1), main/main.cpp:3838-3841
-			const uint32_t c01 = host_srgb_encode(c->hThresh, 0.1f);
-			l.clearColour = c01 | (c01 << 8) | (c01 << 16) | ((uint32_t)floorf(0.1f * 255.0f + 0.5f) << 24);
+			StageTimer t(c, ST_DEFERRED_LIGHT);
 			vkr_launch_deferred_light(c->stream, l);
 		}
 		StageTimer t(c, ST_COPY_OUT);

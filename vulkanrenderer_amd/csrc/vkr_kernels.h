@@ -123,6 +123,7 @@ void vkr_launch_resolve_gbuf(hipStream_t s, const ResolveArgs& a);
 void vkr_launch_resolve_forward(hipStream_t s, const ResolveArgs& a);
 void vkr_launch_resolve_debug(hipStream_t s, const ResolveArgs& a);
 void vkr_launch_deferred_light(hipStream_t s, const LightArgs& a);
+void vkr_launch_resolve_light(hipStream_t s, const ResolveArgs& a, const LightArgs& l); // gN/gA/depth/triId of `a` optional
 void vkr_launch_overvis_colour(hipStream_t s, const uint8_t* stencil, uint32_t* colour, const float* srgbThresh, uint32_t n);
 void vkr_launch_mosaic(hipStream_t s, const uint32_t* src, uint32_t srcX0, uint32_t srcY0, uint32_t srcW, uint32_t srcH,
                        uint32_t* dst, ViewDev view, const float* srgbDecode, const float* srgbThresh);
