@@ -19,6 +19,10 @@
 // (debug views).  Compiled with -ffp-contract=off.
 #include "vkr_kernels.h"
 
+#define ALPHA_DEEP 96   // alpha-tested + many-tile bin entries above which a tile's quadrants are split over ALPHA_SPLIT workgroups
+#define ALPHA_SPLIT 4
+#define ALPHA_BUSY 4096u   // quadrants with alpha-tested entries above which deep tiles are not split
+#define ALPHA_HELPERS 1536u // helper workgroups launched behind the per-quadrant ones: room for 128 deep tiles
 #define BIG_AREA 48 // bbox pixels inside the tile above which a wave takes the sub-triangle
 
 // Edge functions are integer-valued and, with the guard band of
@@ -219,7 +223,18 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 		else if (MODE == RASTER_SHADOW) a.depthOut[p] = u2f(tb32[i]);
 		else a.countOut[p] = (uint8_t)min(tb32[i], 255u); // INCREMENT_AND_CLAMP, main/main.cpp:2783
 	}
-	if (MODE == RASTER_VIS && tid == 0) a.alphaTiles[tile] = (uint32_t)sAnyAlpha;
+	if (MODE == RASTER_VIS && tid == 0) {
+		// 0 = no alpha-tested entries, 1 = some, 2 + k = many: k-th entry of the list of deep tiles, whose
+		// quadrants get helper workgroups in k_raster_alpha
+		uint32_t flag = (uint32_t)sAnyAlpha;
+		if (sAnyAlpha) atomicAdd(a.alphaTileCount, 1u);
+		if (sAnyAlpha && (end - beg) - nO > ALPHA_DEEP) {
+			const uint32_t k = atomicAdd(a.deepTileCount, 1u);
+			a.deepTiles[k] = tile; // the list is as long as the tile array
+			flag = 2u + k;
+		}
+		a.alphaTiles[tile] = flag;
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -316,9 +331,33 @@ __device__ __forceinline__ float alpha_fetch_finish(const AlphaFetch& f, const A
 
 __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a)
 {
-	const uint32_t tile = blockIdx.x / 4;
-	if (!a.alphaTiles[tile]) return;
-	const int qx = (int)(blockIdx.x & 1) * 16, qy = (int)((blockIdx.x >> 1) & 1) * 16; // the quadrant, tile-local
+	// Workgroups [0, 4 * tiles): one per quadrant.  Behind them ALPHA_HELPERS workgroups: (ALPHA_SPLIT - 1) per
+	// quadrant of the first deep tiles.  The entries of a deep tile's bin section are dealt round-robin to the
+	// ALPHA_SPLIT workgroups of a quadrant, each resolves its share from the same starting keys, and the shares
+	// meet in an atomicMin on the visibility buffer (the minimum does not depend on who found it): a tile
+	// with hundreds of overlapping alpha-tested triangles is a chain of dependent alpha tests per 8x8 block,
+	// and at 1920x1080 one such chain was the whole kernel.
+	// Splitting repeats the per-workgroup set-up and weakens the depth rejection (a share does not see what the
+	// other shares found), so it only pays while the GPU has workgroup slots to spare: with more than
+	// ALPHA_BUSY quadrants to do, the kernel is bound by throughput and the tiles are left whole.
+	const uint32_t nQuads = a.view.tilesX * a.view.tilesY * 4u;
+	const bool spare = a.alphaTileCount[0] * 4u <= ALPHA_BUSY;
+	uint32_t tile, quad, sub = 0, split = 1;
+	if (blockIdx.x < nQuads) {
+		tile = blockIdx.x / 4; quad = blockIdx.x & 3u;
+		const uint32_t flag = a.alphaTiles[tile];
+		if (!flag) return;
+		if (spare && flag >= 2u && (flag - 2u) * 4u * (ALPHA_SPLIT - 1u) + 4u * (ALPHA_SPLIT - 1u) <= ALPHA_HELPERS) split = ALPHA_SPLIT;
+	} else {
+		const uint32_t e = blockIdx.x - nQuads;
+		const uint32_t k = e / (4u * (ALPHA_SPLIT - 1u));
+		if (!spare || k >= min(a.deepTileCount[0], nQuads / 4u)) return;
+		tile = a.deepTiles[k];
+		quad = (e / (ALPHA_SPLIT - 1u)) & 3u;
+		sub = 1u + e % (ALPHA_SPLIT - 1u);
+		split = ALPHA_SPLIT;
+	}
+	const int qx = (int)(quad & 1) * 16, qy = (int)((quad >> 1) & 1) * 16; // the quadrant, tile-local
 	__shared__ AlphaCover sCov[ALPHA_STAGE];
 	__shared__ AlphaAttr sAttr[ALPHA_STAGE];
 	__shared__ uint32_t sCount;
@@ -354,13 +393,14 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 	// the alpha-tested section of the bin, then the records that touch many tiles (of either kind)
 	const uint32_t nO = min(a.tileCount[tile], end - beg);
 	beg += nO;
-	const uint32_t n = end - beg;
+	const uint32_t nAll = end - beg;
+	const uint32_t n = (nAll + split - 1u - sub) / split; // this workgroup's share: entries sub, sub + split, ...
 
 	for (uint32_t base = 0; base < n; base += ALPHA_STAGE) {
 		if (tid == 0) sCount = 0;
 		__syncthreads();
 		if (tid < ALPHA_STAGE && base + tid < n) {
-			const uint32_t ri = a.binList[beg + base + tid];
+			const uint32_t ri = a.binList[beg + (base + tid) * split + sub];
 			const SubTri s = a.recs[ri];
 			if (s.flags & VKR_ST_ALPHA) {
 				int bx0, by0, bx1, by1;
@@ -527,7 +567,10 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 		}
 		__syncthreads();
 	}
-	if (inRect && part == 0) a.vis[p] = key;
+	if (inRect && part == 0) {
+		if (split > 1u) atomicMin(&a.vis[p], key);
+		else a.vis[p] = key;
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -612,7 +655,7 @@ void vkr_launch_raster(hipStream_t s, int mode, const RasterArgs& a)
 	if (!nTiles) return;
 	if (mode == RASTER_VIS) {
 		hipLaunchKernelGGL(k_raster<RASTER_VIS>, dim3(nTiles), dim3(256), 0, s, a);
-		if (a.alphaPass) hipLaunchKernelGGL(k_raster_alpha, dim3(nTiles * 4), dim3(256 * ALPHA_PARTS), 0, s, a);
+		if (a.alphaPass) hipLaunchKernelGGL(k_raster_alpha, dim3(nTiles * 4 + ALPHA_HELPERS), dim3(256 * ALPHA_PARTS), 0, s, a);
 	}
 	else if (mode == RASTER_SHADOW) hipLaunchKernelGGL(k_raster<RASTER_SHADOW>, dim3(nTiles), dim3(256), 0, s, a);
 	else hipLaunchKernelGGL(k_raster<RASTER_COUNT>, dim3(nTiles), dim3(256), 0, s, a);

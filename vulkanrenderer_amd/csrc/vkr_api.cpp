@@ -792,11 +792,11 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if ((rc = c->tileCountA.ensure((size_t)nTiles * 4))) return rc;
 	if ((rc = c->tileOffset.ensure((size_t)(nTiles + 1) * 4))) return rc;
 	if ((rc = c->cursor.ensure((size_t)nTiles * 4))) return rc;
-	if ((rc = c->tileFlags.ensure((size_t)nTiles * 4))) return rc;
+	if ((rc = c->tileFlags.ensure((size_t)nTiles * 8))) return rc; // per-tile flags, then the list of deep tiles
 	if ((rc = c->binList.ensure((size_t)binCap * 4))) return rc;
 	if (g.keys && (rc = c->binKeys.ensure((size_t)binCap * 4))) return rc;
 	c->recCap = recCap; c->binCap = binCap;
-	uint32_t* counters = c->counters.as<uint32_t>(); // [0] recCount, [1] overflow, [2] unused, [3] clip queue length, [4] big-record queue length
+	uint32_t* counters = c->counters.as<uint32_t>(); // [0] recCount, [1] overflow, [2] alpha tile count, [3] clip queue length, [4] big-record queue length, [5] deep alpha tile count
 	ZeroArgs z;
 	z.counters = counters; z.tiles0 = c->tileCount.as<uint32_t>(); z.tiles1 = c->tileCountA.as<uint32_t>();
 	z.tiles2 = c->tileCountBig.as<uint32_t>(); z.nTiles = nTiles;
@@ -842,6 +842,7 @@ static void fill_raster_args(vkr_context* c, const vkr_scene* s, const ViewDev& 
 	r.tileOffset = c->tileOffset.as<uint32_t>(); r.tileCount = c->tileCount.as<uint32_t>(); r.tileCountA = c->tileCountA.as<uint32_t>(); r.binList = c->binList.as<uint32_t>(); r.binCap = c->binCap;
 	r.vis = nullptr; r.depthOut = nullptr; r.countOut = nullptr;
 	r.alphaTiles = c->tileFlags.as<uint32_t>(); r.alphaPass = 0;
+	r.deepTiles = c->tileFlags.as<uint32_t>() + (size_t)view.tilesX * view.tilesY; r.deepTileCount = c->counters.as<uint32_t>() + 5; r.alphaTileCount = c->counters.as<uint32_t>() + 2;
 }
 
 static int copy_out(vkr_context* c, void* dst, const void* src, size_t bytes)

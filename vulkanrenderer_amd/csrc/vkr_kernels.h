@@ -71,6 +71,9 @@ struct RasterArgs {
 	float* depthOut;         // RASTER_SHADOW: rect-sized depth
 	uint8_t* countOut;       // RASTER_COUNT: rect-sized saturating counter
 	uint32_t* alphaTiles;    // RASTER_VIS: per tile, 1 if its bin holds alpha-tested sub-triangles (written for every tile)
+	uint32_t* alphaTileCount; // RASTER_VIS: number of tiles flagged in alphaTiles (zeroed with the pass counters)
+	uint32_t* deepTiles;     // RASTER_VIS: the tiles with many alpha-tested entries (capacity: tiles)
+	uint32_t* deepTileCount; // its length (zeroed with the pass counters)
 	int alphaPass;           // RASTER_VIS: run the alpha-tested second pass
 };
 
