@@ -20,9 +20,9 @@
 #include "vkr_kernels.h"
 
 #define ALPHA_DEEP 96   // alpha-tested + many-tile bin entries above which a tile's quadrants are split over ALPHA_SPLIT workgroups
-#define ALPHA_SPLIT 4
+#define ALPHA_SPLIT 8
 #define ALPHA_BUSY 4096u   // quadrants with alpha-tested entries above which deep tiles are not split
-#define ALPHA_HELPERS 1536u // helper workgroups launched behind the per-quadrant ones: room for 128 deep tiles
+#define ALPHA_HELPERS 3584u // helper workgroups launched behind the per-quadrant ones: room for 128 deep tiles
 #define BIG_AREA 48 // bbox pixels inside the tile above which a wave takes the sub-triangle
 
 // Edge functions are integer-valued and, with the guard band of
