@@ -211,7 +211,8 @@ def proxy_small():
     return scenes.proxy_scene(detail=0.02, tex_size=64)
 
 
-@pytest.mark.parametrize("mode,kw", [("deferred", dict(deferred=True)), ("forward", dict(debug=1)), ("mip", dict(debug=2)),
+@pytest.mark.parametrize("mode,kw", [("deferred", dict(deferred=True)), ("deferred-fused", dict(deferred=True, flags=2)),  # VKR_FRAME_FUSED_LIGHTING
+                                     ("forward", dict(debug=1)), ("mip", dict(debug=2)),
                                      ("deriv", dict(debug=4)), ("overdraw", dict(debug=5)), ("overshade", dict(debug=6)),
                                      ("mosaic", dict(mosaic=True))])
 def test_proxy_scene_parity(ctx, proxy_small, mode, kw):
