@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--fused", action="store_true",
                     help="deferred mode: G-buffer resolve and lighting as one kernel (VKR_FRAME_FUSED_LIGHTING); the roofline "
                          "object then describes k_resolve_light with 12 B/pixel (8 read from the visibility buffer, 4 written)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="frames in flight (vkr_context_set_frames_in_flight): consecutive frames run on streams of their own and "
+                         "overlap on the GPU; the lighting kernel's event times then include the kernels it shares the GPU with")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs, collectives on host tensors)")
@@ -150,8 +153,15 @@ def main():
         rect = None
         out_t = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
     rh = (rect[3] - rect[1]) if rect else H
-    fo = abi.FrameOut()
-    fo.rgba8 = out_t.data_ptr()
+    lanes = 1 if sortfirst else max(1, args.lanes)  # sort-first gathers after every frame: nothing to overlap with
+    ctx.set_frames_in_flight(lanes)
+    # one output image per lane, as a swapchain has one image per frame in flight
+    outs = [out_t] + [torch.empty_like(out_t) for _ in range(lanes - 1)]
+    fos = []
+    for o in outs:
+        fo = abi.FrameOut()
+        fo.rgba8 = o.data_ptr()
+        fos.append(fo)
 
     def frame(i):
         # poses: frame i of the fly-through goes to rank i % world; sort-first: every rank renders its band of frame i
@@ -159,7 +169,7 @@ def main():
         u = renderer.make_uniforms(W, H, fly_pose(pose_index % 512), 1)
         p = abi.make_params(W, H, u, rect=rect, **kw)
         if rh > 0:
-            scene.submit(p, fo)
+            scene.submit(p, fos[i % lanes])
         if sortfirst:
             ctx.wait()  # the band must be complete before RCCL reads it on torch's stream
             comp.gather()
@@ -253,7 +263,7 @@ def main():
             "config": {"workload": "SunTemple-proxy v1 %s shading, 21 brazier lights, %dx%d, fly-through poses, whole frame%s" % (
                 args.mode, W, H, (" + %dx%d light depth map" % (args.shadow, args.shadow)) if (args.shadow and args.mode == "deferred") else ""),
                        "triangles": stats["triangles"], "vertices": stats["vertices"], "texture_bytes": stats["texture_bytes"],
-                       "partition": args.partition, "scene_setup_s": round(t_scene, 1)},
+                       "partition": args.partition, "frames_in_flight": lanes, "scene_setup_s": round(t_scene, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if args.profile_all:

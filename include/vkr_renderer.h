@@ -178,6 +178,14 @@ VKR_API const char* vkr_last_error(void);
 /* Creates a context on HIP device `device` with its own stream. */
 VKR_API int vkr_context_create(int device, vkr_context** out);
 VKR_API void vkr_context_destroy(vkr_context* ctx);
+/* Frames in flight.  The reference keeps as many frames in flight as the swapchain has images, each with its own
+ * fence and semaphores (main/main.cpp:466-476, 1263-1296).  With n > 1 the context owns n lanes - HIP stream, scratch
+ * and frame buffers each - and vkr_render hands consecutive frames to consecutive lanes, so the passes of one frame
+ * that leave compute units idle (binning, the tails of the rasteriser) overlap the shading of another.  Frames may
+ * complete out of order: n consecutive frames need n distinct sets of output buffers, as swapchain images are
+ * distinct.  Default 1.  Fails while frames are pending. */
+#define VKR_MAX_FRAMES_IN_FLIGHT 8
+VKR_API int vkr_context_set_frames_in_flight(vkr_context* ctx, uint32_t n);
 
 /* Replaces load_baked_model() + the texture / mesh upload loops
  * (main/baked_model.hpp:117, main/main.cpp:752-760, 870-1095): copies the
@@ -186,6 +194,7 @@ VKR_API int vkr_scene_create(vkr_context* ctx, const vkr_scene_desc* desc, vkr_s
 /* Same, reading a ".comp5892mesh" file (variant "21-tan",
  * main/baked_model.cpp:70-174) and the PNG textures it names. */
 VKR_API int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** out);
+/* Waits for the frames that use the scene, then releases it.  Destroy a context's scenes before the context. */
 VKR_API void vkr_scene_destroy(vkr_scene* scene);
 /* Host-only: decodes one PNG the way the reference's texture loader does,
  * stbi_load(path, &w, &h, &c, 4) after stbi_set_flip_vertically_on_load(1)

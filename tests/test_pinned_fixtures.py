@@ -220,3 +220,19 @@ def test_png_decode_errors(tmp_path):
     open(p, "wb").write(b"not a png at all")
     with pytest.raises(renderer.VkrError):
         renderer.decode_png(p)
+    # headers that promise more than any machine holds, or a depth the colour type does not have, are errors too:
+    # nothing may escape the C ABI as an exception or a crash
+    import struct, zlib
+
+    def png(w, h, depth, ctype, idat=b""):
+        def chunk(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(idat)) + chunk(b"IEND", b""))
+
+    for name, blob in (("huge.png", png(0x7fffffff, 0x7fffffff, 8, 6)), ("big.png", png(1 << 24, 1 << 24, 16, 6)),
+                       ("depth.png", png(2, 2, 4, 2, bytes(8))), ("pal16.png", png(2, 2, 16, 3, bytes(10)))):
+        q = str(tmp_path / name)
+        open(q, "wb").write(blob)
+        with pytest.raises(renderer.VkrError):
+            renderer.decode_png(q)

@@ -162,6 +162,13 @@ def test_errors(ctx, micro, tmp_path):
     bad.write_bytes(b"\0\0COMP5892Mmesh\0" + b"default".ljust(16, b"\0"))
     with pytest.raises(renderer.VkrError, match="variant"):
         renderer.Scene(ctx, path=str(bad))
+    # counts that the rest of the file cannot hold: an error, not an allocation of that size
+    head = b"\0\0COMP5892Mmesh\0" + b"21-tan".ljust(16, b"\0")
+    for tail in (b"\xff\xff\xff\xff", b"\0\0\0\0" + b"\xff\xff\xff\x7f", b"\0\0\0\0" * 2 + b"\xff\xff\xff\xff",
+                 b"\0\0\0\0" * 2 + b"\1\0\0\0" + b"\0\0\0\0" + b"\xff\xff\xff\xff" * 2):
+        bad.write_bytes(head + tail)
+        with pytest.raises(renderer.VkrError, match="unexpected end of file"):
+            renderer.Scene(ctx, path=str(bad))
     m = dict(micro.meshes[0])
     m["indices"] = m["indices"].copy()
     m["indices"][2] = 10 ** 6
@@ -203,6 +210,66 @@ def test_frames_in_flight(ctx, micro):
     for a, b in zip(single, bufs):
         assert np.array_equal(a, b)
     sc.close()
+
+
+def test_frames_in_flight_on_lanes(micro):
+    """vkr_context_set_frames_in_flight: consecutive frames run on lanes of their own (stream, scratch, frame
+    buffers) and may overlap; every frame equals the one a single-lane context renders."""
+    from vulkanrenderer_amd import abi, renderer
+    c = renderer.Context(0)
+    sc = renderer.Scene(c, micro)
+    jobs = []
+    for i in range(7):
+        W, H = (96, 54) if i % 2 else (160, 90)
+        kw = [dict(deferred=True), dict(), dict(debug=6), dict(deferred=True, flags=abi.FRAME_FUSED_LIGHTING), dict(mosaic=True)][i % 5]
+        jobs.append(params(W, H, pose_matrix(0.1 * i, -0.2, -0.5 * i, 0.1 * i), shadow=128, **kw))
+    single = [sc.render(p, want=("rgba8", "tri_id")) for p in jobs]
+    with pytest.raises(renderer.VkrError):
+        c.set_frames_in_flight(0)
+    with pytest.raises(renderer.VkrError):
+        c.set_frames_in_flight(99)
+    c.set_frames_in_flight(3)
+    c.profile(True)
+    for rounds in range(2):  # the second round reuses the lanes' buffers
+        outs = []
+        for p in jobs:
+            img = np.zeros((p.height, p.width, 4), np.uint8)
+            tid = np.full((p.height, p.width), 0xFFFFFFFF, np.uint32)  # the prefill Scene.render uses (views 5, 6 write no ids)
+            fo = abi.FrameOut()
+            fo.rgba8 = img.ctypes.data
+            fo.tri_id = tid.ctypes.data
+            sc.submit(p, fo)
+            outs.append((img, tid))
+        with pytest.raises(renderer.VkrError, match="pending"):
+            c.set_frames_in_flight(2)
+        c.wait()
+        for ref, (img, tid) in zip(single, outs):
+            assert np.array_equal(ref["rgba8"], img) and np.array_equal(ref["tri_id"], tid)
+    rep = c.profile_report()
+    assert rep["k_xform"][1] >= 2 * len(jobs)  # stage timers of every lane are summed
+    c.set_frames_in_flight(1)
+    again = sc.render(jobs[0], want=("rgba8",))["rgba8"]
+    assert np.array_equal(again, single[0]["rgba8"])
+    sc.close()
+    c.close()
+
+
+def test_unclosed_handles_exit_cleanly():
+    """A host that forgets vkr_scene_destroy / vkr_context_destroy (here: a lane context with a frame in flight)
+    still exits with status 0: the wrappers release what is open before the interpreter goes down."""
+    import subprocess
+    import sys
+    code = ("import numpy as np\n"
+            "from vulkanrenderer_amd import abi, renderer, scenes\n"
+            "c = renderer.Context(0); c.set_frames_in_flight(2)\n"
+            "s = renderer.Scene(c, scenes.micro_scene())\n"
+            "u = renderer.make_uniforms(64, 36, [1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,0,1], 1)\n"
+            "img = np.zeros((36, 64, 4), np.uint8); fo = abi.FrameOut(); fo.rgba8 = img.ctypes.data\n"
+            "s.submit(abi.make_params(64, 36, u, deferred=True), fo)\n"
+            "print('submitted')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "submitted" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
 
 
 @pytest.fixture(scope="module")

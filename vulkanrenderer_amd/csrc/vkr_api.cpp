@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -44,6 +46,16 @@ int vkr_set_error_ext(int code, const char* fmt, ...)
 	vsnprintf(g_err, sizeof g_err, fmt, ap);
 	va_end(ap);
 	return code;
+}
+
+// No exception may leave the library: the containers used on the host side can throw (std::bad_alloc,
+// std::length_error); every entry point that touches them runs its body under this guard.
+template <class F> static int guarded(const char* fn, F&& body) noexcept
+{
+	try { return body(); }
+	catch (const std::bad_alloc&) { return set_error(VKR_E_NOMEM, "%s: out of host memory", fn); }
+	catch (const std::exception& e) { return set_error(VKR_E_INVALID, "%s: %s", fn, e.what()); }
+	catch (...) { return set_error(VKR_E_INVALID, "%s: unknown exception", fn); }
 }
 
 // ---------------------------------------------------------------------------
@@ -112,6 +124,11 @@ struct vkr_context {
 	std::vector<hipEvent_t> eventPool;
 	double stageMs[ST_COUNT] = { 0 };
 	uint64_t stageLaunches[ST_COUNT] = { 0 };
+	// frames in flight: lane 0 is this context, lanes 1.. are contexts of their own (stream, scratch, frame buffers)
+	// on the same device that only this one hands frames to
+	std::vector<vkr_context*> lanes;
+	vkr_context* parent = nullptr;
+	uint32_t nextLane = 0;
 };
 
 struct HostTex { uint32_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS], off[VKR_MAX_LEVELS]; int levels; int srgb; };
@@ -387,6 +404,8 @@ extern "C" int vkr_context_create(int device, vkr_context** out)
 extern "C" void vkr_context_destroy(vkr_context* c)
 {
 	if (!c) return;
+	for (vkr_context* l : c->lanes) vkr_context_destroy(l);
+	c->lanes.clear();
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	DevBuf* bufs[] = { &c->clip, &c->planes, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->bigQueue, &c->counters, &c->tileCount, &c->tileCountA, &c->tileCountBig, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
@@ -445,27 +464,40 @@ extern "C" int vkr_profile_enable(vkr_context* c, int on)
 {
 	if (!c) return set_error(VKR_E_INVALID, "NULL context");
 	c->profiling = on;
+	for (vkr_context* l : c->lanes) l->profiling = on;
 	return VKR_OK;
 }
-extern "C" int vkr_profile_reset(vkr_context* c)
+static int profile_reset_impl(vkr_context* c)
 {
 	if (!c) return set_error(VKR_E_INVALID, "NULL context");
 	HIP_CHECK(hipSetDevice(c->device));
 	HIP_CHECK(hipStreamSynchronize(c->stream));
 	drain_timers(c);
 	for (int i = 0; i < ST_COUNT; i++) { c->stageMs[i] = 0; c->stageLaunches[i] = 0; }
+	for (vkr_context* l : c->lanes) {
+		int rc = profile_reset_impl(l);
+		if (rc) return rc;
+	}
 	return VKR_OK;
 }
 extern "C" int vkr_stage_count(void) { return ST_COUNT; }
 extern "C" const char* vkr_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
-extern "C" int vkr_profile_get(vkr_context* c, int stage, double* ms, uint64_t* launches)
+static int profile_get_impl(vkr_context* c, int stage, double* ms, uint64_t* launches)
 {
 	if (!c || stage < 0 || stage >= ST_COUNT) return set_error(VKR_E_INVALID, "bad stage");
 	HIP_CHECK(hipSetDevice(c->device));
 	HIP_CHECK(hipStreamSynchronize(c->stream));
 	drain_timers(c);
-	if (ms) *ms = c->stageMs[stage];
-	if (launches) *launches = c->stageLaunches[stage];
+	double total = c->stageMs[stage];
+	uint64_t n = c->stageLaunches[stage];
+	for (vkr_context* l : c->lanes) {
+		double lm = 0.0; uint64_t ln = 0;
+		int rc = profile_get_impl(l, stage, &lm, &ln);
+		if (rc) return rc;
+		total += lm; n += ln;
+	}
+	if (ms) *ms = total;
+	if (launches) *launches = n;
 	return VKR_OK;
 }
 
@@ -483,13 +515,17 @@ static int mip_level_count(uint32_t w, uint32_t h)
 extern "C" void vkr_scene_destroy(vkr_scene* s)
 {
 	if (!s) return;
-	if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
+	if (s->ctx) {
+		(void)hipSetDevice(s->ctx->device);
+		(void)hipStreamSynchronize(s->ctx->stream);
+		for (vkr_context* l : s->ctx->lanes) (void)hipStreamSynchronize(l->stream);
+	}
 	DevBuf* bufs[] = { &s->pos, &s->uv, &s->tcomp, &s->tbn, &s->tri, &s->triMat, &s->orderB, &s->tex, &s->mat, &s->texels, &s->alphaTexels, &s->alphaAux };
 	for (DevBuf* b : bufs) b->release();
 	delete s;
 }
 
-extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_scene** out)
+static int scene_create_impl(vkr_context* c, const vkr_scene_desc* d, vkr_scene** out)
 {
 	if (!c || !d || !out) return set_error(VKR_E_INVALID, "vkr_scene_create: NULL argument");
 	*out = nullptr;
@@ -528,7 +564,9 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 	if (!s) return set_error(VKR_E_NOMEM, "out of host memory");
 	s->ctx = c; s->nTri = nTri; s->nVert = nVert;
 	int rc = VKR_OK;
-	auto fail = [&](int code) { vkr_scene_destroy(s); return code; };
+	// released on every exit that does not hand the scene to the caller (error returns and exceptions alike)
+	struct Owner { vkr_scene* s; ~Owner() { if (s) vkr_scene_destroy(s); } } owner{ s };
+	auto fail = [&](int code) { return code; };
 
 	// ---- geometry: vertices concatenated in file order; triangles in
 	// submission order A = opaque meshes first, then alpha-masked meshes
@@ -714,6 +752,7 @@ extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_sce
 		hipError_t e = hipStreamSynchronize(c->stream);
 		if (e != hipSuccess) return fail(set_error(VKR_E_DEVICE, "mip generation: %s", hipGetErrorString(e)));
 	}
+	owner.s = nullptr;
 	*out = s;
 	return VKR_OK;
 }
@@ -1130,10 +1169,16 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 	return VKR_OK;
 }
 
-extern "C" int vkr_render(vkr_context* c, const vkr_scene* s, const vkr_frame_params* fp, const vkr_frame_out* out)
+static int render_impl(vkr_context* c, const vkr_scene* s, const vkr_frame_params* fp, const vkr_frame_out* out)
 {
 	if (!c || !s || !fp || !out) return set_error(VKR_E_INVALID, "vkr_render: NULL argument");
-	if (s->ctx != c) return set_error(VKR_E_INVALID, "vkr_render: scene belongs to another context");
+	if (s->ctx != c && s->ctx != c->parent) return set_error(VKR_E_INVALID, "vkr_render: scene belongs to another context");
+	if (!c->lanes.empty()) {
+		// frames go round the lanes in submission order; the scene is read-only while rendering
+		const uint32_t k = c->nextLane;
+		c->nextLane = (k + 1) % (uint32_t)(c->lanes.size() + 1);
+		if (k) return render_impl(c->lanes[k - 1], s, fp, out);
+	}
 	HIP_CHECK(hipSetDevice(c->device));
 	int rc;
 	if ((rc = ensure_status(c, 2))) return rc;
@@ -1146,7 +1191,7 @@ extern "C" int vkr_render(vkr_context* c, const vkr_scene* s, const vkr_frame_pa
 	return VKR_OK;
 }
 
-extern "C" int vkr_wait(vkr_context* c)
+static int wait_impl(vkr_context* c)
 {
 	if (!c) return set_error(VKR_E_INVALID, "vkr_wait: NULL context");
 	HIP_CHECK(hipSetDevice(c->device));
@@ -1183,4 +1228,62 @@ extern "C" int vkr_wait(vkr_context* c)
 	c->pending.clear();
 	c->statusUsed = 0;
 	return set_error(VKR_E_LIMIT, "tile bins still overflow after growing the scratch buffers");
+}
+
+// ---------------------------------------------------------------------------
+// guarded entry points
+// ---------------------------------------------------------------------------
+extern "C" int vkr_scene_create(vkr_context* c, const vkr_scene_desc* d, vkr_scene** out)
+{
+	return guarded("vkr_scene_create", [&] { return scene_create_impl(c, d, out); });
+}
+extern "C" int vkr_render(vkr_context* c, const vkr_scene* s, const vkr_frame_params* fp, const vkr_frame_out* out)
+{
+	return guarded("vkr_render", [&] { return render_impl(c, s, fp, out); });
+}
+extern "C" int vkr_wait(vkr_context* c)
+{
+	return guarded("vkr_wait", [&] {
+		int rc = wait_impl(c);
+		if (c)
+			for (vkr_context* l : c->lanes) {
+				const int r = wait_impl(l);
+				if (r && !rc) rc = r;
+			}
+		return rc;
+	});
+}
+
+static int set_lanes_impl(vkr_context* c, uint32_t n)
+{
+	if (!c || c->parent) return set_error(VKR_E_INVALID, "vkr_context_set_frames_in_flight: not a context created by vkr_context_create");
+	if (n < 1 || n > VKR_MAX_FRAMES_IN_FLIGHT) return set_error(VKR_E_LIMIT, "vkr_context_set_frames_in_flight: %u lanes (1..%d)", n, VKR_MAX_FRAMES_IN_FLIGHT);
+	bool busy = !c->pending.empty();
+	for (vkr_context* l : c->lanes) busy = busy || !l->pending.empty();
+	if (busy) return set_error(VKR_E_INVALID, "vkr_context_set_frames_in_flight: frames are pending, call vkr_wait first");
+	while (c->lanes.size() + 1 > n) { vkr_context_destroy(c->lanes.back()); c->lanes.pop_back(); }
+	c->lanes.reserve(n);
+	while (c->lanes.size() + 1 < n) {
+		vkr_context* l = nullptr;
+		int rc = vkr_context_create(c->device, &l);
+		if (rc) return rc;
+		l->parent = c;
+		l->profiling = c->profiling;
+		c->lanes.push_back(l);
+	}
+	c->nextLane = 0;
+	return VKR_OK;
+}
+
+extern "C" int vkr_context_set_frames_in_flight(vkr_context* c, uint32_t n)
+{
+	return guarded("vkr_context_set_frames_in_flight", [&] { return set_lanes_impl(c, n); });
+}
+extern "C" int vkr_profile_reset(vkr_context* c)
+{
+	return guarded("vkr_profile_reset", [&] { return profile_reset_impl(c); });
+}
+extern "C" int vkr_profile_get(vkr_context* c, int stage, double* ms, uint64_t* launches)
+{
+	return guarded("vkr_profile_get", [&] { return profile_get_impl(c, stage, ms, launches); });
 }

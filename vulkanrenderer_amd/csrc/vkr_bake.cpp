@@ -491,7 +491,7 @@ void write_string(FILE* f, const std::string& s)
 
 extern "C" const char* vkr_bake_last_error(void) { return g_err; }
 
-extern "C" int vkr_index_mesh(const float* positions, const float* normals, const float* texcoords, uint32_t n, float tolerance,
+static int index_mesh_entry(const float* positions, const float* normals, const float* texcoords, uint32_t n, float tolerance,
                               vkr_indexed_mesh* out)
 {
 	if (!positions || !normals || !texcoords || !out) return fail("vkr_index_mesh: NULL argument");
@@ -523,7 +523,7 @@ extern "C" void vkr_indexed_mesh_free(vkr_indexed_mesh* m)
 	std::memset(m, 0, sizeof *m);
 }
 
-extern "C" int vkr_bake_obj(const char* obj_path, const char* out_path, int copy_textures)
+static int bake_obj_entry(const char* obj_path, const char* out_path, int copy_textures)
 {
 	namespace fs = std::filesystem;
 	if (!obj_path || !out_path) return fail("vkr_bake_obj: NULL path");
@@ -561,7 +561,8 @@ extern "C" int vkr_bake_obj(const char* obj_path, const char* out_path, int copy
 	if (!rootdir.empty()) fs::create_directories(rootdir, ec);
 	fs::path mainpath = rootdir / outname.stem();
 	mainpath.replace_extension("comp5892mesh");
-	FILE* f = std::fopen(mainpath.string().c_str(), "wb");
+	struct File { FILE* f; ~File() { if (f) std::fclose(f); } } file{ std::fopen(mainpath.string().c_str(), "wb") };
+	FILE* f = file.f;
 	if (!f) return fail("unable to open '%s' for writing", mainpath.string().c_str());
 	// write_model_data_, main-bake/main.cpp:276-389
 	static const char kMagic[16] = "\0\0COMP5892Mmesh";
@@ -592,10 +593,31 @@ extern "C" int vkr_bake_obj(const char* obj_path, const char* out_path, int copy
 		std::fwrite(m.idx.data(), 4, m.idx.size(), f);
 	}
 	const bool bad = std::ferror(f) != 0;
+	file.f = nullptr;
 	if (std::fclose(f) != 0 || bad) return fail("writing '%s' failed", mainpath.string().c_str());
 	if (copy_textures) {
 		fs::create_directories(rootdir / texdir, ec);
 		for (const TexEntry& t : textures) fs::copy_file(t.srcPath, rootdir / t.newPath, fs::copy_options::none, ec); // existing files are kept
 	}
 	return 0;
+}
+
+// No exception may leave the library (std::bad_alloc, std::filesystem errors, ...).
+template <class F> static int guarded(const char* fn, F&& body) noexcept
+{
+	try { return body(); }
+	catch (const std::bad_alloc&) { return fail("%s: out of host memory", fn); }
+	catch (const std::exception& e) { return fail("%s: %s", fn, e.what()); }
+	catch (...) { return fail("%s: unknown exception", fn); }
+}
+
+extern "C" int vkr_index_mesh(const float* positions, const float* normals, const float* texcoords, uint32_t n, float tolerance,
+                              vkr_indexed_mesh* out)
+{
+	return guarded("vkr_index_mesh", [&] { return index_mesh_entry(positions, normals, texcoords, n, tolerance, out); });
+}
+
+extern "C" int vkr_bake_obj(const char* obj_path, const char* out_path, int copy_textures)
+{
+	return guarded("vkr_bake_obj", [&] { return bake_obj_entry(obj_path, out_path, copy_textures); });
 }

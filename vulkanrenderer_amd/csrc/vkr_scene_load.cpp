@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -93,6 +95,9 @@ std::string decode_png(const std::vector<uint8_t>& file, std::vector<uint8_t>& r
 	default: return "bad colour type";
 	}
 	if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) return "bad bit depth";
+	// depths below 8 exist for grey and palette images only, 16 not for palettes (PNG specification, table 11.1)
+	if ((depth < 8 && ctype != 0 && ctype != 3) || (depth == 16 && ctype == 3)) return "bad bit depth for the colour type";
+	if (W > (1u << 24) || H > (1u << 24)) return "image too large"; // stb_image's own limit (STBI_MAX_DIMENSIONS)
 	const size_t bpp = (size_t)channels * depth;           // bits per pixel
 	const size_t stride = ((size_t)W * bpp + 7) / 8;       // bytes per row
 	const size_t fbpp = (bpp + 7) / 8;                     // filter distance in bytes
@@ -161,7 +166,7 @@ std::string decode_png(const std::vector<uint8_t>& file, std::vector<uint8_t>& r
 
 } // namespace
 
-extern "C" int vkr_decode_png_file(const char* path, uint8_t** rgba8, uint32_t* width, uint32_t* height)
+static int decode_png_file_impl(const char* path, uint8_t** rgba8, uint32_t* width, uint32_t* height)
 {
 	if (!path || !rgba8 || !width || !height) return vkr_set_error_ext(VKR_E_INVALID, "vkr_decode_png_file: NULL argument");
 	*rgba8 = nullptr;
@@ -179,7 +184,7 @@ extern "C" void vkr_free(void* p) { free(p); }
 
 // A frame as an 8-bit RGBA PNG (filter 0 on every row, zlib level 6).  Rows are written top first, the order
 // vkr_render delivers them in; flip = 1 writes them bottom first (the order vkr_decode_png_file returns).
-extern "C" int vkr_write_png_file(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height, int flip)
+static int write_png_file_impl(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height, int flip)
 {
 	if (!path || !rgba8 || !width || !height) return vkr_set_error_ext(VKR_E_INVALID, "vkr_write_png_file: NULL argument or empty image");
 	const size_t stride = (size_t)width * 4;
@@ -218,7 +223,7 @@ extern "C" int vkr_write_png_file(const char* path, const uint8_t* rgba8, uint32
 	return VKR_OK;
 }
 
-extern "C" int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** out)
+static int scene_load_impl(vkr_context* ctx, const char* path, vkr_scene** out)
 {
 	if (!ctx || !path || !out) return vkr_set_error_ext(VKR_E_INVALID, "vkr_scene_load: NULL argument");
 	*out = nullptr;
@@ -240,6 +245,8 @@ extern "C" int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** ou
 
 	uint32_t nTex = 0;
 	if (!rd.u32(nTex)) return truncated();
+	// a count the rest of the file cannot hold is a truncated (or hostile) file, not a reason to allocate for it
+	if ((uint64_t)nTex * 6 > rd.n - rd.off) return truncated();
 	struct Tex { std::string path; uint8_t space, channels; std::vector<uint8_t> rgba; uint32_t w = 0, h = 0; };
 	std::vector<Tex> tex(nTex);
 	for (auto& t : tex) {
@@ -255,11 +262,13 @@ extern "C" int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** ou
 	}
 	uint32_t nMat = 0;
 	if (!rd.u32(nMat)) return truncated();
+	if ((uint64_t)nMat * sizeof(vkr_material_desc) > rd.n - rd.off) return truncated();
 	std::vector<vkr_material_desc> mats(nMat);
 	for (auto& m : mats)
 		if (!rd.take(&m, sizeof m)) return truncated();
 	uint32_t nMesh = 0;
 	if (!rd.u32(nMesh)) return truncated();
+	if ((uint64_t)nMesh * 12 > rd.n - rd.off) return truncated();
 	struct Mesh { uint32_t mat, V, I; size_t pos, nrm, uv, tan, tc, idx; };
 	std::vector<Mesh> meshes(nMesh);
 	for (auto& m : meshes) {
@@ -306,4 +315,25 @@ extern "C" int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** ou
 	d.textureCount = nTex; d.materialCount = nMat; d.meshCount = nMesh;
 	d.textures = td.data(); d.materials = mats.data(); d.meshes = md.data();
 	return vkr_scene_create(ctx, &d, out);
+}
+
+// No exception may leave the library (std::bad_alloc / std::length_error from the containers above).
+template <class F> static int guarded(const char* fn, F&& body) noexcept
+{
+	try { return body(); }
+	catch (const std::bad_alloc&) { return vkr_set_error_ext(VKR_E_NOMEM, "%s: out of host memory", fn); }
+	catch (const std::exception& e) { return vkr_set_error_ext(VKR_E_INVALID, "%s: %s", fn, e.what()); }
+	catch (...) { return vkr_set_error_ext(VKR_E_INVALID, "%s: unknown exception", fn); }
+}
+extern "C" int vkr_decode_png_file(const char* path, uint8_t** rgba8, uint32_t* width, uint32_t* height)
+{
+	return guarded("vkr_decode_png_file", [&] { return decode_png_file_impl(path, rgba8, width, height); });
+}
+extern "C" int vkr_write_png_file(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height, int flip)
+{
+	return guarded("vkr_write_png_file", [&] { return write_png_file_impl(path, rgba8, width, height, flip); });
+}
+extern "C" int vkr_scene_load(vkr_context* ctx, const char* path, vkr_scene** out)
+{
+	return guarded("vkr_scene_load", [&] { return scene_load_impl(ctx, path, out); });
 }

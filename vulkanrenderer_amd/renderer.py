@@ -3,8 +3,10 @@
 There is no fallback path: if the HIP library is missing or fails to load the
 import of this module's users fails loudly.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -20,7 +22,7 @@ EXPORTS = [
     "vkr_update_scene_uniforms", "vkr_update_depth_mvp_uniforms", "vkr_default_lights", "vkr_make_uniforms",
     "vkr_profile_enable", "vkr_profile_reset", "vkr_stage_count", "vkr_stage_name", "vkr_profile_get",
     "vkr_context_stream", "vkr_decode_png_file", "vkr_free", "vkr_write_png_file",
-    "vkr_user_state_init", "vkr_update_user_state",
+    "vkr_user_state_init", "vkr_update_user_state", "vkr_context_set_frames_in_flight",
 ]
 
 
@@ -70,6 +72,7 @@ def lib():
         L.vkr_free.restype = None
         L.vkr_context_stream.restype = C.c_void_p
         L.vkr_context_stream.argtypes = [C.c_void_p]
+        L.vkr_context_set_frames_in_flight.argtypes = [C.c_void_p, C.c_uint32]
         _lib = L
     return _lib
 
@@ -128,14 +131,32 @@ def write_png(path, rgba8, flip=False):
 SIDE = ("rgba8", "tri_id", "depth_bits", "mip_level", "stencil", "gbuf_normal", "gbuf_albedo", "shadow_map")
 
 
+# Handles still open when the interpreter exits are released here, scenes first: a destructor that runs during
+# interpreter teardown would call into a HIP runtime that may already be gone.
+_live_scenes = weakref.WeakSet()
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_handles():
+    for s in list(_live_scenes):
+        s.close()
+    for c in list(_live_contexts):
+        c.close()
+
+
 class Context:
     def __init__(self, device=0):
         self.h = C.c_void_p()
         _check(lib().vkr_context_create(device, C.byref(self.h)))
         self.device = device
+        self._scenes = weakref.WeakSet()
+        _live_contexts.add(self)
 
     def close(self):
         if self.h:
+            for s in list(self._scenes):  # a scene must not outlive the context whose stream and tables it uses
+                s.close()
             lib().vkr_context_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -147,6 +168,11 @@ class Context:
 
     def wait(self):
         _check(lib().vkr_wait(self.h))
+
+    def set_frames_in_flight(self, n):
+        """n lanes (stream + scratch + frame buffers each); consecutive frames go to consecutive lanes and may
+        overlap on the GPU, so n consecutive frames need n distinct output buffers."""
+        _check(lib().vkr_context_set_frames_in_flight(self.h, int(n)))
 
     @property
     def stream(self):
@@ -175,6 +201,8 @@ class Scene:
             _check(lib().vkr_scene_create(ctx.h, C.byref(packed.desc), C.byref(self.h)))
         else:
             _check(lib().vkr_scene_load(ctx.h, path.encode(), C.byref(self.h)))
+        ctx._scenes.add(self)
+        _live_scenes.add(self)
 
     def close(self):
         if self.h:
