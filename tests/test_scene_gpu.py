@@ -184,6 +184,32 @@ def test_errors(ctx, micro, tmp_path):
     sc.close()
 
 
+def test_non_finite_vertices_are_dropped(ctx, micro):
+    """Triangles with a NaN vertex are dropped by triangle setup; infinite and huge coordinates go through the clipper
+    without leaving the frame's tiles.  Nothing faults, and NaN triangles leave the image as it was."""
+    from vulkanrenderer_amd import abi, renderer
+    base = renderer.Scene(ctx, micro)
+    nan_mesh = dict(micro.meshes[0])
+    nan_mesh["positions"] = np.full_like(micro.meshes[0]["positions"], np.nan)
+    wild = dict(micro.meshes[0])
+    pos = micro.meshes[0]["positions"].copy()
+    pos[0::5, 0] = np.inf
+    pos[1::5, 1] = -np.inf
+    pos[2::5, 2] = 3.0e38
+    pos[3::5] = -1.0e30
+    wild["positions"] = pos
+    with_nan = renderer.Scene(ctx, abi.PackedScene(micro.textures, micro.materials, [micro.meshes[0], nan_mesh] + list(micro.meshes[1:])))
+    with_wild = renderer.Scene(ctx, abi.PackedScene(micro.textures, micro.materials, list(micro.meshes) + [wild]))
+    for kw in (dict(deferred=True), dict(), dict(debug=2), dict(debug=5), dict(debug=6), dict(mosaic=True)):
+        p = params(160, 90, pose_matrix(0.3, -0.2, -1.5, 0.2), shadow=128, **kw)
+        a, b = base.render(p), with_nan.render(p)
+        for k in ("rgba8", "depth_bits", "stencil", "mip_level"):
+            assert np.array_equal(a[k], b[k]), (kw, k)
+        c = with_wild.render(p)
+        assert c["rgba8"].shape == a["rgba8"].shape
+    base.close(); with_nan.close(); with_wild.close()
+
+
 def test_empty_scene_renders_clear_colour(ctx, micro):
     from vulkanrenderer_amd import abi, renderer
     sc = renderer.Scene(ctx, abi.PackedScene(micro.textures, micro.materials, []))
