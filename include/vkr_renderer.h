@@ -186,6 +186,10 @@ VKR_API void vkr_context_destroy(vkr_context* ctx);
  * distinct.  Default 1.  Fails while frames are pending. */
 #define VKR_MAX_FRAMES_IN_FLIGHT 8
 VKR_API int vkr_context_set_frames_in_flight(vkr_context* ctx, uint32_t n);
+/* The per-image fence of the reference's loop (vkWaitForFences(frameDone[frameIndex]), main/main.cpp:1268): blocks
+ * until the lane the next vkr_render will use has finished the frames it holds, i.e. until the output buffers
+ * handed over n frames ago are complete and may be reused.  With one lane it is vkr_wait. */
+VKR_API int vkr_wait_next_lane(vkr_context* ctx);
 
 /* Replaces load_baked_model() + the texture / mesh upload loops
  * (main/baked_model.hpp:117, main/main.cpp:752-760, 870-1095): copies the

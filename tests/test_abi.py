@@ -74,3 +74,18 @@ def test_png_write_then_decode_roundtrip(tmp_path):
     assert np.array_equal(back[::-1], img)
     renderer.write_png(p, img, flip=True)
     assert np.array_equal(renderer.decode_png(p), img)
+
+
+def test_c_host_builds_and_fails_cleanly_without_a_gpu():
+    """tools/vkr_bench.c: the header is plain C99 and a C host links against the library with gcc alone; without a
+    GPU the host reports the library's error and exits 1 (no fallback), without arguments it prints its usage."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "tools")], stdout=subprocess.DEVNULL)
+    exe = os.path.join(root, "tools", "vkr_bench")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "usage" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, os.path.join(root, "tests", "golden", "micro.comp5892mesh")], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "vkr_context_create" in r.stderr, (r.returncode, r.stderr)

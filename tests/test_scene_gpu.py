@@ -298,6 +298,29 @@ def test_unclosed_handles_exit_cleanly():
     assert r.returncode == 0 and "submitted" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
 
 
+def test_c_host_renders_the_same_frames(ctx, tmp_path):
+    """tools/vkr_bench (plain C, gcc) drives the library through the C ABI alone: scene file in, frames in flight,
+    PNG out; its last frame equals the one the Python binding renders for the same pose."""
+    import subprocess
+    from vulkanrenderer_amd import abi, renderer
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "vkr_bench")
+    assert os.path.exists(exe), "build tools/vkr_bench first (make -C tools, or __graft_entry__.build())"
+    scene_path = os.path.join(GOLD, "micro.comp5892mesh")
+    sc = renderer.Scene(ctx, path=scene_path)
+    W, H = 160, 90
+    for mode, kw, lanes in (("deferred", dict(deferred=True), 2), ("mosaic", dict(mosaic=True), 3), ("debug6", dict(debug=6), 1)):
+        png = str(tmp_path / (mode + ".png"))
+        r = subprocess.run([exe, scene_path, "--width", str(W), "--height", str(H), "--frames", "7", "--first", "3", "--mode", mode,
+                            "--lanes", str(lanes), "--png", png], capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0 and "frames_per_s" in r.stdout, (r.returncode, r.stdout, r.stderr)
+        got = renderer.decode_png(png)[::-1]  # the decoder returns rows bottom first
+        ref = sc.render(params(W, H, bench.fly_pose(3 + 6), shadow=2048, **kw), want=("rgba8",))["rgba8"]  # the host leaves shadow_size 0 = 2048
+        assert np.array_equal(got, ref), mode
+    sc.close()
+
+
 @pytest.fixture(scope="module")
 def proxy_small():
     from vulkanrenderer_amd import scenes

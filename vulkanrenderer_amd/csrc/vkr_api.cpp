@@ -1254,6 +1254,14 @@ extern "C" int vkr_wait(vkr_context* c)
 	});
 }
 
+extern "C" int vkr_wait_next_lane(vkr_context* c)
+{
+	return guarded("vkr_wait_next_lane", [&] {
+		if (!c) return set_error(VKR_E_INVALID, "vkr_wait_next_lane: NULL context");
+		return wait_impl(c->nextLane ? c->lanes[c->nextLane - 1] : c);
+	});
+}
+
 static int set_lanes_impl(vkr_context* c, uint32_t n)
 {
 	if (!c || c->parent) return set_error(VKR_E_INVALID, "vkr_context_set_frames_in_flight: not a context created by vkr_context_create");

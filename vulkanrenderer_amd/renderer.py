@@ -23,6 +23,7 @@ EXPORTS = [
     "vkr_profile_enable", "vkr_profile_reset", "vkr_stage_count", "vkr_stage_name", "vkr_profile_get",
     "vkr_context_stream", "vkr_decode_png_file", "vkr_free", "vkr_write_png_file",
     "vkr_user_state_init", "vkr_update_user_state", "vkr_context_set_frames_in_flight",
+    "vkr_wait_next_lane",
 ]
 
 
@@ -73,6 +74,7 @@ def lib():
         L.vkr_context_stream.restype = C.c_void_p
         L.vkr_context_stream.argtypes = [C.c_void_p]
         L.vkr_context_set_frames_in_flight.argtypes = [C.c_void_p, C.c_uint32]
+        L.vkr_wait_next_lane.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -168,6 +170,10 @@ class Context:
 
     def wait(self):
         _check(lib().vkr_wait(self.h))
+
+    def wait_next_lane(self):
+        """Waits until the lane the next frame goes to is idle: the buffers handed over n frames ago are complete."""
+        _check(lib().vkr_wait_next_lane(self.h))
 
     def set_frames_in_flight(self, n):
         """n lanes (stream + scratch + frame buffers each); consecutive frames go to consecutive lanes and may
