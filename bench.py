@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=1,
                     help="frames in flight (vkr_context_set_frames_in_flight): consecutive frames run on streams of their own and "
                          "overlap on the GPU; the lighting kernel's event times then include the kernels it shares the GPU with")
+    ap.add_argument("--readback", default="none", choices=["none", "pinned", "pageable"],
+                    help="deliver every frame into host memory (the PCIe-inclusive rate; the headline value keeps frames in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs, collectives on host tensors)")
@@ -157,6 +159,8 @@ def main():
     ctx.set_frames_in_flight(lanes)
     # one output image per lane, as a swapchain has one image per frame in flight
     outs = [out_t] + [torch.empty_like(out_t) for _ in range(lanes - 1)]
+    if args.readback != "none" and not sortfirst:
+        outs = [torch.empty(out_t.shape, dtype=torch.uint8, pin_memory=(args.readback == "pinned")) for _ in range(lanes)]
     fos = []
     for o in outs:
         fo = abi.FrameOut()
@@ -263,7 +267,7 @@ def main():
             "config": {"workload": "SunTemple-proxy v1 %s shading, 21 brazier lights, %dx%d, fly-through poses, whole frame%s" % (
                 args.mode, W, H, (" + %dx%d light depth map" % (args.shadow, args.shadow)) if (args.shadow and args.mode == "deferred") else ""),
                        "triangles": stats["triangles"], "vertices": stats["vertices"], "texture_bytes": stats["texture_bytes"],
-                       "partition": args.partition, "frames_in_flight": lanes, "scene_setup_s": round(t_scene, 1)},
+                       "partition": args.partition, "frames_in_flight": lanes, "readback": args.readback, "scene_setup_s": round(t_scene, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if args.profile_all:
