@@ -384,6 +384,33 @@ def test_properties_at_full_resolution(ctx):
     sc.close()
 
 
+def test_frames_in_flight_at_full_resolution():
+    """Three lanes, 3840x2160, fly-through poses of the proxy scene, mixed modes: overlapped frames equal the frames
+    rendered one at a time, byte for byte (no state is shared between frames in flight but the read-only scene)."""
+    from bench import fly_pose
+    from vulkanrenderer_amd import abi, renderer, scenes
+    c = renderer.Context(0)
+    sc = renderer.Scene(c, scenes.proxy_scene(detail=0.25, tex_size=128))
+    W, H = 3840, 2160
+    kws = [dict(deferred=True), dict(deferred=True, flags=abi.FRAME_FUSED_LIGHTING), dict(), dict(deferred=True), dict(debug=6), dict(deferred=True)]
+    jobs = [params(W, H, fly_pose(40 * i), shadow=1024, **kw) for i, kw in enumerate(kws)]
+    single = [sc.render(p, want=("rgba8", "depth_bits")) for p in jobs]
+    c.set_frames_in_flight(3)
+    outs = []
+    for p in jobs:
+        img, z = np.zeros((H, W, 4), np.uint8), np.zeros((H, W), np.uint32)
+        fo = abi.FrameOut()
+        fo.rgba8, fo.depth_bits = img.ctypes.data, z.ctypes.data
+        c.wait_next_lane()
+        sc.submit(p, fo)
+        outs.append((img, z))
+    c.wait()
+    for i, (ref, (img, z)) in enumerate(zip(single, outs)):
+        assert np.array_equal(ref["rgba8"], img) and np.array_equal(ref["depth_bits"], z), "frame %d" % i
+    sc.close()
+    c.close()
+
+
 def test_full_scene_1080p_against_oracle(ctx):
     """The benchmark's own workload - every triangle of the SunTemple-proxy (smaller textures), fly-through poses of
     bench.py - at 1920x1080 against the oracle: integer buffers bit-exact, colour within 1/255."""
