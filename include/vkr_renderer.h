@@ -255,9 +255,26 @@ typedef struct vkr_user_state {
 	float mouseX, mouseY;
 	float previousX, previousY;
 	float camera2world[16];            /* column-major, identity at start */
+	/* the mode fields the key callback sets (main/main.cpp:117-120); `shadows` is toggled but never read by the
+	 * reference's draw code */
+	int32_t debugVisualisation;        /* 1 at start */
+	int32_t mosaicEffect, deferredShading, shadows;
 } vkr_user_state;
-/* Zeroes the inputs and sets camera2world to identity (main/main.cpp:124). */
+/* Zeroes the inputs, sets camera2world to identity and debugVisualisation to 1 (main/main.cpp:111-125). */
 VKR_API void vkr_user_state_init(vkr_user_state* state);
+/* The three GLFW callbacks that feed UserState, for hosts that replay a recorded event stream.  Key, button and
+ * action values are GLFW's (GLFW_KEY_W = 87, GLFW_KEY_1 = 49, GLFW_KEY_LEFT_SHIFT = 340, ...; GLFW_RELEASE = 0,
+ * GLFW_PRESS = 1, GLFW_REPEAT = 2; GLFW_MOUSE_BUTTON_RIGHT = 1).
+ *   key:    glfw_callback_key_press (main/main.cpp:1422-1514): on release 1-4 pick the view, 5 toggles mosaic, 6 / 7
+ *           pick overdraw / overshading, 8 toggles deferred shading, 9 toggles shadows; W S A D E Q, shift, control
+ *           are held while not released.  Returns 1 if the key was escape pressed (the reference closes the window).
+ *   button: glfw_callback_button (main/main.cpp:1516-1529): a right-button press toggles mouse look.
+ *   motion: glfw_callback_motion (main/main.cpp:1531-1537). */
+VKR_API int vkr_user_state_key(vkr_user_state* state, int key, int action);
+VKR_API void vkr_user_state_button(vkr_user_state* state, int button, int action);
+VKR_API void vkr_user_state_motion(vkr_user_state* state, double x, double y);
+/* Copies the mode fields into the frame parameters, as main() hands them to record_commands (main/main.cpp:1367-1389). */
+VKR_API void vkr_frame_params_set_modes(vkr_frame_params* params, const vkr_user_state* state);
 /* One step of update_user_state (main/main.cpp:3643-3679): mouse look while
  * `mousing` is held on two consecutive steps (0.01 rad per pixel, pitch then
  * yaw, post-multiplied), then translation by elapsedSeconds * 1.7 (x7 fast,

@@ -144,6 +144,52 @@ def test_replay_inputs_yields_renderable_poses():
     assert more.shape == (1, 16)
 
 
+def test_replay_events_follows_the_glfw_callbacks():
+    """vkr_user_state_key / _button / _motion restate glfw_callback_key_press, glfw_callback_button and
+    glfw_callback_motion (main/main.cpp:1422-1537): view keys act on release, 5 and 8 toggle, movement keys are held
+    while not released (a repeat keeps them held), a right-button press toggles mouse look."""
+    from vulkanrenderer_amd import abi, renderer
+    R, P, RP = renderer.GLFW_RELEASE, renderer.GLFW_PRESS, renderer.GLFW_REPEAT
+    ev = [("frame", 0.1),
+          ("key", "2", P), ("frame", 0.1),                       # a press alone changes nothing
+          ("key", "2", R), ("frame", 0.1),                       # mip view on release
+          ("key", "8", R), ("frame", 0.1),                       # deferred on (takes precedence in record_commands)
+          ("key", "8", R), ("key", "7", R), ("key", "5", R), ("frame", 0.1),   # deferred off, overshading, mosaic on
+          ("key", "5", R), ("key", "1", R),
+          ("key", "w", P), ("frame", 0.5), ("key", "w", RP), ("frame", 0.5), ("key", "w", R), ("frame", 0.5),
+          ("key", renderer.GLFW_KEY_RIGHT_SHIFT, P), ("key", "E", P), ("frame", 1.0),
+          ("key", renderer.GLFW_KEY_RIGHT_SHIFT, R), ("key", "E", R),
+          ("button", 0, P), ("button", renderer.GLFW_MOUSE_BUTTON_RIGHT, R), ("frame", 0.1),   # neither toggles
+          ("button", renderer.GLFW_MOUSE_BUTTON_RIGHT, P), ("motion", 100.0, 50.0), ("frame", 0.1),
+          ("motion", 110.0, 50.0), ("frame", 0.1)]
+    frames, closed, st = renderer.replay_events(ev)
+    modes = [m for _, m in frames]
+    assert not closed and len(frames) == 12
+    assert modes[0] == modes[1] == dict(debug=1, mosaic=False, deferred=False)
+    assert modes[2] == dict(debug=2, mosaic=False, deferred=False)
+    assert modes[3] == dict(debug=2, mosaic=False, deferred=True)
+    assert modes[4] == dict(debug=6, mosaic=True, deferred=False)
+    assert modes[5] == dict(debug=1, mosaic=False, deferred=False)
+    z = [float(c[14]) for c, _ in frames]
+    step = float(np.float32(0.5) * np.float32(1.7))
+    assert z[4] == 0.0 and abs(z[5] + step) < 1e-6 and abs(z[6] + 2 * step) < 1e-6 and z[7] == z[6]   # held through the repeat
+    y = [float(c[13]) for c, _ in frames]
+    assert abs(y[8] - 1.7 * 7.0) < 1e-4 and y[9] == y[8]                                              # levitate, fast
+    assert st.inputMap[abi.INPUT_KEYS.index("mousing")] == 1
+    assert np.array_equal(frames[10][0], frames[9][0])        # the first mousing frame only latches the cursor
+    assert not np.array_equal(frames[11][0][:12], frames[10][0][:12]) and st.mouseX == 110.0
+    # the poses equal the ones update_user_state gives for the same held keys (pinned against glm elsewhere)
+    ref, _ = renderer.replay_inputs([(set(), 0, 0, 0.1)] * 5 + [({"forward"}, 0, 0, 0.5)] * 2 + [(set(), 0, 0, 0.5)]
+                                    + [({"fast", "levitate"}, 0, 0, 1.0), (set(), 0, 0, 0.1), ({"mousing"}, 100.0, 50.0, 0.1),
+                                       ({"mousing"}, 110.0, 50.0, 0.1)])
+    assert np.array_equal(ref, np.array([c for c, _ in frames]))
+    _, closed, _ = renderer.replay_events([("key", renderer.GLFW_KEY_ESCAPE, P)])
+    assert closed
+    p = abi.FrameParams()
+    renderer.lib().vkr_frame_params_set_modes(p, st)
+    assert (p.debugVisualisation, p.mosaicEffect, p.deferredShading) == (1, 0, 0)
+
+
 def test_tbn_packer_matches_make_indexed_mesh():
     """main-bake/index_mesh.cpp:178-220 run on a 30-vertex mesh through tgen."""
     from oracle import oracle

@@ -81,13 +81,15 @@ INPUT_KEYS = ("forward", "backward", "strafeLeft", "strafeRight", "levitate", "s
 
 
 class UserState(C.Structure):
-    """vkr_user_state: the camera part of the reference's UserState (main/main.cpp:111-125)."""
+    """vkr_user_state: the reference's UserState (main/main.cpp:111-125)."""
     _fields_ = [("inputMap", C.c_uint8 * 9), ("wasMousing", C.c_uint8), ("_pad", C.c_uint8 * 2),
                 ("mouseX", C.c_float), ("mouseY", C.c_float), ("previousX", C.c_float), ("previousY", C.c_float),
-                ("camera2world", C.c_float * 16)]
+                ("camera2world", C.c_float * 16),
+                ("debugVisualisation", C.c_int32), ("mosaicEffect", C.c_int32), ("deferredShading", C.c_int32),
+                ("shadows", C.c_int32)]
 
 
-assert C.sizeof(UserState) == 92
+assert C.sizeof(UserState) == 108
 assert C.sizeof(SceneUniform) == 208 and C.sizeof(LightUniform) == 32
 assert C.sizeof(MultipleLights) == 672 and C.sizeof(DepthMVP) == 64
 assert C.sizeof(TextureDesc) == 24 and C.sizeof(MaterialDesc) == 24 and C.sizeof(MeshDesc) == 64

@@ -340,6 +340,59 @@ extern "C" void vkr_user_state_init(vkr_user_state* st)
 {
 	memset(st, 0, sizeof *st);
 	st->camera2world[0] = st->camera2world[5] = st->camera2world[10] = st->camera2world[15] = 1.0f;
+	st->debugVisualisation = 1;
+}
+
+// glfw_callback_key_press, main/main.cpp:1422-1514 (key and action values of GLFW/glfw3.h)
+extern "C" int vkr_user_state_key(vkr_user_state* st, int key, int action)
+{
+	if (!st) return 0;
+	const bool isReleased = (action == 0);
+	if (isReleased) {
+		switch (key) {
+		case '1': case '2': case '3': case '4': st->debugVisualisation = key - '0'; break;
+		case '5': st->mosaicEffect = !st->mosaicEffect; break;
+		case '6': st->debugVisualisation = 5; break;
+		case '7': st->debugVisualisation = 6; break;
+		case '8': st->deferredShading = !st->deferredShading; break;
+		case '9': st->shadows = !st->shadows; break;
+		default: break;
+		}
+	}
+	switch (key) {
+	case 'W': st->inputMap[VKR_INPUT_FORWARD] = !isReleased; break;
+	case 'S': st->inputMap[VKR_INPUT_BACKWARD] = !isReleased; break;
+	case 'A': st->inputMap[VKR_INPUT_STRAFE_LEFT] = !isReleased; break;
+	case 'D': st->inputMap[VKR_INPUT_STRAFE_RIGHT] = !isReleased; break;
+	case 'E': st->inputMap[VKR_INPUT_LEVITATE] = !isReleased; break;
+	case 'Q': st->inputMap[VKR_INPUT_SINK] = !isReleased; break;
+	case 340: case 344: st->inputMap[VKR_INPUT_FAST] = !isReleased; break; // left / right shift
+	case 341: case 345: st->inputMap[VKR_INPUT_SLOW] = !isReleased; break; // left / right control
+	default: break;
+	}
+	return (key == 256 && action == 1) ? 1 : 0; // escape pressed
+}
+
+// glfw_callback_button, main/main.cpp:1516-1529
+extern "C" void vkr_user_state_button(vkr_user_state* st, int button, int action)
+{
+	if (st && button == 1 && action == 1) st->inputMap[VKR_INPUT_MOUSING] = !st->inputMap[VKR_INPUT_MOUSING];
+}
+
+// glfw_callback_motion, main/main.cpp:1531-1537
+extern "C" void vkr_user_state_motion(vkr_user_state* st, double x, double y)
+{
+	if (!st) return;
+	st->mouseX = (float)x;
+	st->mouseY = (float)y;
+}
+
+extern "C" void vkr_frame_params_set_modes(vkr_frame_params* fp, const vkr_user_state* st)
+{
+	if (!fp || !st) return;
+	fp->debugVisualisation = st->debugVisualisation;
+	fp->mosaicEffect = st->mosaicEffect;
+	fp->deferredShading = st->deferredShading;
 }
 
 extern "C" void vkr_update_user_state(vkr_user_state* st, float elapsed)

@@ -23,7 +23,8 @@ EXPORTS = [
     "vkr_profile_enable", "vkr_profile_reset", "vkr_stage_count", "vkr_stage_name", "vkr_profile_get",
     "vkr_context_stream", "vkr_decode_png_file", "vkr_free", "vkr_write_png_file",
     "vkr_user_state_init", "vkr_update_user_state", "vkr_context_set_frames_in_flight",
-    "vkr_wait_next_lane",
+    "vkr_wait_next_lane", "vkr_user_state_key", "vkr_user_state_button", "vkr_user_state_motion",
+    "vkr_frame_params_set_modes",
 ]
 
 
@@ -69,6 +70,13 @@ def lib():
         L.vkr_user_state_init.restype = None
         L.vkr_update_user_state.argtypes = [C.POINTER(abi.UserState), C.c_float]
         L.vkr_update_user_state.restype = None
+        L.vkr_user_state_key.argtypes = [C.POINTER(abi.UserState), C.c_int, C.c_int]
+        L.vkr_user_state_button.argtypes = [C.POINTER(abi.UserState), C.c_int, C.c_int]
+        L.vkr_user_state_button.restype = None
+        L.vkr_user_state_motion.argtypes = [C.POINTER(abi.UserState), C.c_double, C.c_double]
+        L.vkr_user_state_motion.restype = None
+        L.vkr_frame_params_set_modes.argtypes = [C.POINTER(abi.FrameParams), C.POINTER(abi.UserState)]
+        L.vkr_frame_params_set_modes.restype = None
         L.vkr_free.argtypes = [C.c_void_p]
         L.vkr_free.restype = None
         L.vkr_context_stream.restype = C.c_void_p
@@ -112,6 +120,40 @@ def replay_inputs(trace, state=None):
         L.vkr_update_user_state(C.byref(state), dt)
         poses.append(np.array(state.camera2world, np.float32))
     return np.array(poses, np.float32).reshape(-1, 16), state
+
+
+# GLFW's values (GLFW/glfw3.h), as the reference's callbacks receive them
+GLFW_RELEASE, GLFW_PRESS, GLFW_REPEAT = 0, 1, 2
+GLFW_MOUSE_BUTTON_RIGHT = 1
+GLFW_KEY_ESCAPE, GLFW_KEY_LEFT_SHIFT, GLFW_KEY_LEFT_CONTROL, GLFW_KEY_RIGHT_SHIFT, GLFW_KEY_RIGHT_CONTROL = 256, 340, 341, 344, 345
+
+
+def replay_events(events, state=None):
+    """Replays a recorded GLFW event stream through the reference's three callbacks and its per-frame update
+    (main/main.cpp:1422-1537, 3643-3679).  events: ("key", key, action) with key an int or a one-character string,
+    ("button", button, action), ("motion", x, y), ("frame", dt).  Returns one (camera2world float32[16], dict of the
+    three mode fields) per "frame" event, whether escape was pressed, and the final state."""
+    L = lib()
+    if state is None:
+        state = abi.UserState()
+        L.vkr_user_state_init(C.byref(state))
+    frames, closed = [], False
+    for ev in events:
+        kind = ev[0]
+        if kind == "key":
+            key = ord(ev[1].upper()) if isinstance(ev[1], str) else int(ev[1])
+            closed = bool(L.vkr_user_state_key(C.byref(state), key, int(ev[2]))) or closed
+        elif kind == "button":
+            L.vkr_user_state_button(C.byref(state), int(ev[1]), int(ev[2]))
+        elif kind == "motion":
+            L.vkr_user_state_motion(C.byref(state), float(ev[1]), float(ev[2]))
+        elif kind == "frame":
+            L.vkr_update_user_state(C.byref(state), float(ev[1]))
+            frames.append((np.array(state.camera2world, np.float32),
+                           dict(debug=state.debugVisualisation, mosaic=bool(state.mosaicEffect), deferred=bool(state.deferredShading))))
+        else:
+            raise ValueError("unknown event %r" % (kind,))
+    return frames, closed, state
 
 
 def decode_png(path):
