@@ -625,20 +625,32 @@ __global__ __launch_bounds__(1024) void k_overshade(OvershadeArgs a)
 		}
 		__syncthreads();
 		const uint32_t m = min((uint32_t)ALPHA_CHUNK, n - base);
-		for (uint32_t j = 0; j < m; j++) {
-			const AlphaCover& c = sCov[j];
-			const uint32_t bb = c.bbox;
-			const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
-			if (x1 < bxl || x0 > bxl + 7 || y1 < byl || y0 > byl + 7) continue; // misses the block (wave-uniform)
-			const double e0 = fma(c.sy0, dly, fma(c.sx0, dlx, c.e0));
-			const double e1 = fma(c.sy1, dly, fma(c.sx1, dlx, c.e1));
-			const double e2 = fma(c.sy2, dly, fma(c.sx2, dlx, c.e2));
-			if (!(inRect && lx >= x0 && lx <= x1 && ly >= y0 && ly <= y1 && edges_inside(e0, e1, e2))) continue;
-			const float z = vkr_depth_at(c.Az, c.Bz, c.Cz, px, py);
-			if (!(z >= 0.0f && z <= 1.0f)) continue;
-			if (!(z <= depth)) continue;
-			depth = z;
-			if (cnt < 255u) cnt++;
+		for (uint32_t j0 = 0; j0 < m; j0 += 64u) {
+			// 64 entries at a time: every lane tests one entry's bounding box against the wavefront's block; the
+			// entries that touch the block are then walked in order (the bits of the ballot, lowest first)
+			bool hit = false;
+			if (j0 + lane < m) {
+				const uint32_t bb = sCov[j0 + lane].bbox;
+				const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
+				hit = !(x1 < bxl || x0 > bxl + 7 || y1 < byl || y0 > byl + 7);
+			}
+			unsigned long long mask = __ballot(hit);
+			while (mask) {
+				const uint32_t j = j0 + (uint32_t)(__ffsll((long long)mask) - 1);
+				mask &= mask - 1;
+				const AlphaCover& c = sCov[j];
+				const uint32_t bb = c.bbox;
+				const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
+				const double e0 = fma(c.sy0, dly, fma(c.sx0, dlx, c.e0));
+				const double e1 = fma(c.sy1, dly, fma(c.sx1, dlx, c.e1));
+				const double e2 = fma(c.sy2, dly, fma(c.sx2, dlx, c.e2));
+				if (!(inRect && lx >= x0 && lx <= x1 && ly >= y0 && ly <= y1 && edges_inside(e0, e1, e2))) continue;
+				const float z = vkr_depth_at(c.Az, c.Bz, c.Cz, px, py);
+				if (!(z >= 0.0f && z <= 1.0f)) continue;
+				if (!(z <= depth)) continue;
+				depth = z;
+				if (cnt < 255u) cnt++;
+			}
 		}
 	}
 	if (inRect) {
