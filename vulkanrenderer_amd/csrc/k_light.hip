@@ -83,8 +83,12 @@ __global__ __launch_bounds__(256) void k_mosaic(const uint32_t* __restrict__ src
 	sDec[threadIdx.x] = decode[threadIdx.x];
 	__syncthreads();
 	const uint32_t rw = view.x1 - view.x0, rh = view.y1 - view.y0;
-	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-	if (x >= rw || y >= rh) return;
+	// 16 x 64 pixels per workgroup, four rows per thread: the two tables are loaded once for all of them
+	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15);
+	if (x >= rw) return;
+	for (uint32_t r = 0; r < 4; r++) {
+	const uint32_t y = blockIdx.y * 64 + r * 16 + (threadIdx.x >> 4);
+	if (y >= rh) return;
 	const int W = (int)view.W, H = (int)view.H;
 	const float sx = (float)W, sy = (float)H;
 	const float kw = 5.0f / sx, kh = 3.0f / sy;
@@ -96,8 +100,11 @@ __global__ __launch_bounds__(256) void k_mosaic(const uint32_t* __restrict__ src
 	const float fxp = su * sx - 0.5f, fyp = sv * sy - 0.5f;
 	const float x0f = floorf(fxp), y0f = floorf(fyp);
 	const float fx = fxp - x0f, fy = fyp - y0f;
-	int x0 = vkr_wrap((int)x0f, W), x1 = vkr_wrap((int)x0f + 1, W);
-	int y0 = vkr_wrap((int)y0f, H), y1 = vkr_wrap((int)y0f + 1, H);
+	// REPEAT addressing; the clamped coordinate keeps the texel index inside [-1, size], so the wrap is one
+	// conditional add or subtract instead of a remainder by a size that is no power of two
+	int x0 = (int)x0f, x1 = x0 + 1, y0 = (int)y0f, y1 = y0 + 1;
+	x0 += (x0 < 0) ? W : 0; x1 -= (x1 >= W) ? W : 0;
+	y0 += (y0 < 0) ? H : 0; y1 -= (y1 >= H) ? H : 0;
 	// the source rectangle holds every texel a block of this rectangle can touch
 	x0 = min(max(x0 - (int)srcX0, 0), (int)srcW - 1); x1 = min(max(x1 - (int)srcX0, 0), (int)srcW - 1);
 	y0 = min(max(y0 - (int)srcY0, 0), (int)srcH - 1); y1 = min(max(y1 - (int)srcY0, 0), (int)srcH - 1);
@@ -118,6 +125,7 @@ __global__ __launch_bounds__(256) void k_mosaic(const uint32_t* __restrict__ src
 		c[k] = vkr_lerp(vkr_lerp(a00, a10, fx), vkr_lerp(a01, a11, fx), fy);
 	}
 	dst[(size_t)y * rw + x] = vkr_pack_colour_lds(sT, c[0], c[1], c[2], c[3]);
+	}
 }
 
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* dst, uint32_t value, size_t n)
@@ -148,7 +156,7 @@ void vkr_launch_overvis_colour(hipStream_t s, const uint8_t* stencil, uint32_t* 
 void vkr_launch_mosaic(hipStream_t s, const uint32_t* src, uint32_t srcX0, uint32_t srcY0, uint32_t srcW, uint32_t srcH,
                        uint32_t* dst, ViewDev view, const float* srgbDecode, const float* srgbThresh)
 {
-	dim3 g((view.x1 - view.x0 + 15) / 16, (view.y1 - view.y0 + 15) / 16);
+	dim3 g((view.x1 - view.x0 + 15) / 16, (view.y1 - view.y0 + 63) / 64);
 	hipLaunchKernelGGL(k_mosaic, g, dim3(256), 0, s, src, srcX0, srcY0, srcW, srcH, dst, view, srgbDecode, srgbThresh);
 }
 
