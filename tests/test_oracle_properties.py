@@ -115,6 +115,76 @@ def test_brdf_known_answers(L):
             assert np.allclose(np.array(list(out)), want, rtol=2e-3, atol=1e-5)
 
 
+def deferred_np(gn, ga, depth, u, W, H):
+    """deferredShading.frag:34-119 over a whole G-buffer, vectorised in float64 and written from the shader's
+    formulas independently of the oracle's loop: position from depth through the two inverses (:34-41), view vector,
+    re-normalised normal (:105), the BRDF with nDotH floored at 0 (:43-90), and per light
+    (ambient + brdf * 10 * colour * max(N.L, 0)) / d^2 with the alpha channel accumulating 1 / d^2 (:112-116)."""
+    PI = 3.14159265359
+    cam = np.array(u.sceneUniforms.camera, np.float64).reshape(4, 4).T     # column-major storage
+    proj = np.array(u.sceneUniforms.projection, np.float64).reshape(4, 4).T
+    ys, xs = np.mgrid[0:H, 0:W]
+    clip = np.stack([(xs + 0.5) / W * 2 - 1, (ys + 0.5) / H * 2 - 1, depth.astype(np.float64), np.ones((H, W))], -1)
+    view = clip @ (np.linalg.inv(cam) @ np.linalg.inv(proj)).T
+    pos = view[..., :3] / view[..., 3:]
+    V = np.array(list(u.sceneUniforms.camPos)[:3]) - pos
+    V /= np.linalg.norm(V, axis=-1, keepdims=True)
+    N = gn[..., :3].astype(np.float64)
+    N /= np.linalg.norm(N, axis=-1, keepdims=True)
+    metal, alb, rt = gn[..., 3:4].astype(np.float64), ga[..., :3].astype(np.float64), ga[..., 3:4].astype(np.float64)
+    r2 = (rt * rt) ** 2
+    dot = lambda a, b: np.sum(a * b, -1, keepdims=True)
+    col = np.zeros((H, W, 4))
+    for i in range(21):
+        li = u.multipleLightsUniform.light[i]
+        Lv = np.array(list(li.lightPos)[:3]) - pos
+        d2 = dot(Lv, Lv)
+        Ld = Lv / np.sqrt(d2)
+        Hv = V + Ld
+        Hv /= np.linalg.norm(Hv, axis=-1, keepdims=True)
+        nh = np.maximum(dot(N, Hv), 0.0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            D = np.exp((nh * nh - 1) / (r2 * nh * nh)) / (0.001 + PI * r2 * nh ** 4)
+            D = np.where(nh == 0, 0.0, D)                                       # exp(-inf)
+            f0 = (1 - metal) * 0.04 + metal * alb
+            F = f0 + (1 - f0) * (1 - dot(Hv, V)) ** 5
+            G = np.minimum(1, np.minimum(2 * nh * np.maximum(0, dot(N, V)) / dot(V, Hv), 2 * nh * np.maximum(0, dot(N, Ld)) / dot(V, Hv)))
+            brdf = (alb / PI) * (1 - F) * (1 - metal) + D * F * G / (0.001 + 4 * np.maximum(dot(N, V), 0) * np.maximum(dot(N, Ld), 0))
+        ndl = np.maximum(dot(N, Ld), 0.0)
+        colour = np.array(list(li.lightColour)[:3])
+        col[..., :3] += (0.03 * alb + brdf * 10 * colour * ndl) / d2
+        col[..., 3:] += 1.0 / d2
+    return col
+
+
+def srgb8_np(c):
+    c = np.clip(c, 0.0, 1.0)
+    rgb = np.where(c[..., :3] <= 0.0031308, c[..., :3] * 12.92, 1.055 * np.power(c[..., :3], 1 / 2.4) - 0.055)
+    return np.concatenate([np.floor(rgb * 255 + 0.5), np.floor(c[..., 3:] * 255 + 0.5)], -1).astype(np.uint8)
+
+
+def test_deferred_pass_against_an_independent_float64_restatement(micro_oracle):
+    """The oracle's lighting pass over its own G-buffer equals a vectorised float64 evaluation of
+    deferredShading.frag written separately from it (within one 8-bit step; undrawn pixels keep the clear colour)."""
+    from vulkanrenderer_amd import abi
+    from oracle import oracle
+    W, H = 96, 54
+    worst = 0
+    for pose in (IDENTITY, pose_matrix(0.5, -0.3, -2.0, 0.4, -0.15), pose_matrix(0.0, -0.5, -9.0, 3.0)):
+        u = oracle.make_uniforms(W, H, pose, 1)
+        r = micro_oracle.render(abi.make_params(W, H, u, deferred=True))
+        gn = r["gbuf_normal"].view(np.float16).astype(np.float32)
+        ga = r["gbuf_albedo"].view(np.float16).astype(np.float32)
+        depth = r["depth_bits"].view(np.float32)
+        want = srgb8_np(deferred_np(gn, ga, depth, u, W, H))
+        drawn = depth != 1.0
+        assert drawn.mean() > 0.3
+        d = np.abs(want[drawn].astype(np.int32) - r["rgba8"][drawn].astype(np.int32))
+        worst = max(worst, int(d.max()))
+        assert d.max() <= 1, "lighting differs by %d/255 at %d pixels" % (int(d.max()), int((d > 1).sum()))
+    assert worst <= 1
+
+
 # ---------------------------------------------------------------- rasterisation rules
 def cover(L, tris, W, H, cull=0):
     mask = np.zeros((H, W), np.uint8)

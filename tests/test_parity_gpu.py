@@ -89,6 +89,26 @@ def test_committed_golden_frames(gpu):
             assert np.array_equal(gold[k], got[k]), "%s differs at %d pixels" % (k, int((gold[k] != got[k]).sum()))
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_lighting_kernel_against_float64_restatement(gpu, fused):
+    """k_deferred_light (and the fused kernel) over the G-buffer the HIP path itself wrote, against the vectorised
+    float64 evaluation of deferredShading.frag in tests/test_oracle_properties.py: within one 8-bit step."""
+    from test_oracle_properties import deferred_np, srgb8_np
+    from vulkanrenderer_amd import abi, renderer
+    ctx, sc = gpu
+    W, H = 160, 90
+    for pose in POSES.values():
+        u = renderer.make_uniforms(W, H, pose, 1)
+        r = sc.render(abi.make_params(W, H, u, deferred=True, flags=abi.FRAME_FUSED_LIGHTING if fused else 0))
+        gn = r["gbuf_normal"].view(np.float16).astype(np.float32)
+        ga = r["gbuf_albedo"].view(np.float16).astype(np.float32)
+        depth = r["depth_bits"].view(np.float32)
+        want = srgb8_np(deferred_np(gn, ga, depth, u, W, H))
+        drawn = depth != 1.0
+        d = np.abs(want[drawn].astype(np.int32) - r["rgba8"][drawn].astype(np.int32))
+        assert drawn.any() and d.max() <= 1, "lighting differs by %d/255 at %d pixels" % (int(d.max()), int((d > 1).sum()))
+
+
 def test_deferred_with_shadow_pass_flag(gpu, micro_oracle):
     """VKR_FRAME_SHADOW_PASS: the deferred frame is unchanged and the light's depth map equals the forward path's
     (and the oracle's)."""
