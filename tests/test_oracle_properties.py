@@ -359,6 +359,37 @@ def test_mosaic_blocks_and_determinism(micro_oracle):
     assert len(np.unique(a.reshape(-1, 4), axis=0)) > 10
 
 
+def mosaic_np(img):
+    """postProcess.frag:9-25 over an R8G8B8A8_SRGB image, written separately from the oracle: block coordinates in
+    float32 as the shader computes them, then one bilinear fetch (sRGB decoded before filtering, REPEAT addressing)."""
+    H, W = img.shape[:2]
+    f = np.float32
+    u = (np.arange(W, dtype=f) + f(0.5)) / f(W)
+    v = (np.arange(H, dtype=f) + f(0.5)) / f(H)
+    kw, kh = f(5.0) / f(W), f(3.0) / f(H)
+    su = np.clip(kw * np.floor(u / kw), f(0.5) / f(W), f(1) - f(0.5) / f(W))
+    sv = np.clip(kh * np.floor(v / kh), f(0.5) / f(H), f(1) - f(0.5) / f(H))
+    fx, fy = su * f(W) - f(0.5), sv * f(H) - f(0.5)
+    x0, y0 = np.floor(fx).astype(int), np.floor(fy).astype(int)
+    wx, wy = (fx - np.floor(fx)).astype(np.float64)[None, :, None], (fy - np.floor(fy)).astype(np.float64)[:, None, None]
+    c = img.astype(np.float64) / 255.0
+    lin = np.concatenate([np.where(c[..., :3] <= 0.04045, c[..., :3] / 12.92, ((c[..., :3] + 0.055) / 1.055) ** 2.4), c[..., 3:]], -1)
+    X0, X1, Y0, Y1 = x0 % W, (x0 + 1) % W, y0 % H, (y0 + 1) % H
+    top = lin[Y0][:, X0] * (1 - wx) + lin[Y0][:, X1] * wx
+    bot = lin[Y1][:, X0] * (1 - wx) + lin[Y1][:, X1] * wx
+    return srgb8_np(top * (1 - wy) + bot * wy)
+
+
+def test_mosaic_against_an_independent_restatement(micro_oracle):
+    """Mosaic frame = postProcess.frag applied to the forward frame of the same pose (the offscreen image)."""
+    for W, H in ((100, 60), (96, 54), (131, 77)):
+        pose = pose_matrix(0.5, -0.3, -2.0, 0.4, -0.15)
+        fwd = render(micro_oracle, W=W, H=H, pose=pose)["rgba8"]
+        mo = render(micro_oracle, W=W, H=H, pose=pose, mosaic=True)["rgba8"]
+        d = np.abs(mosaic_np(fwd).astype(np.int32) - mo.astype(np.int32))
+        assert d.max() <= 1, "%dx%d: mosaic differs by %d/255 at %d pixels" % (W, H, int(d.max()), int((d > 1).sum()))
+
+
 def test_mip_view_levels_and_derivative_view(micro_oracle):
     m = render(micro_oracle, debug=2)
     cov = m["tri_id"] != 0xFFFFFFFF

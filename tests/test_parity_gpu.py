@@ -109,6 +109,20 @@ def test_lighting_kernel_against_float64_restatement(gpu, fused):
         assert drawn.any() and d.max() <= 1, "lighting differs by %d/255 at %d pixels" % (int(d.max()), int((d > 1).sum()))
 
 
+def test_mosaic_kernel_against_independent_restatement(gpu):
+    """k_mosaic's frame = postProcess.frag (numpy restatement in tests/test_oracle_properties.py) applied to the
+    forward frame the HIP path renders for the same pose."""
+    from test_oracle_properties import mosaic_np
+    from vulkanrenderer_amd import abi, renderer
+    ctx, sc = gpu
+    for W, H in ((160, 90), (131, 77)):
+        u = renderer.make_uniforms(W, H, POSES["p1"], 1)
+        fwd = sc.render(abi.make_params(W, H, u, shadow_size=256), want=("rgba8",))["rgba8"]
+        mo = sc.render(abi.make_params(W, H, u, shadow_size=256, mosaic=True), want=("rgba8",))["rgba8"]
+        d = np.abs(mosaic_np(fwd).astype(np.int32) - mo.astype(np.int32))
+        assert d.max() <= 1, "%dx%d: mosaic differs by %d/255 at %d pixels" % (W, H, int(d.max()), int((d > 1).sum()))
+
+
 def test_deferred_with_shadow_pass_flag(gpu, micro_oracle):
     """VKR_FRAME_SHADOW_PASS: the deferred frame is unchanged and the light's depth map equals the forward path's
     (and the oracle's)."""
