@@ -390,6 +390,49 @@ def test_mosaic_against_an_independent_restatement(micro_oracle):
         assert d.max() <= 1, "%dx%d: mosaic differs by %d/255 at %d pixels" % (W, H, int(d.max()), int((d > 1).sum()))
 
 
+def lin_np(d):
+    return (2.0 * 0.1 * 100.0) / (100.0 + 0.1 - (2.0 * d - 1.0) * (100.0 - 0.1))     # debug.frag:15-17
+
+
+def check_views_from_side_buffers(render_fn):
+    """Three views whose colour is a function of the integer side buffers alone, restated in numpy:
+    depth view (debug.frag:39-42) and derivative view (:43-52, fine differences inside 2x2 quads, checked where a
+    quad lies inside one triangle) from `depth_bits`; overdraw / overshading colour (overVisRead.frag:7-13) from
+    `stencil`.  render_fn(debug=...) -> buffers."""
+    r = render_fn(debug=3)
+    z = r["depth_bits"].view(np.float32).astype(np.float64)
+    drawn = r["tri_id"] != 0xFFFFFFFF
+    assert drawn.mean() > 0.3
+    g = lin_np(z) / 100.0
+    want = srgb8_np(np.stack([g, g, g, np.ones_like(g)], -1))
+    assert np.abs(want[drawn].astype(np.int32) - r["rgba8"][drawn].astype(np.int32)).max() <= 1
+    r4 = render_fn(debug=4)
+    assert np.array_equal(r4["depth_bits"], r["depth_bits"])
+    t = r["tri_id"]
+    H, W = t.shape
+    He, We = H & ~1, W & ~1
+    q = t[:He, :We].reshape(He // 2, 2, We // 2, 2)
+    same = (q == q[:, :1, :, :1]).all(axis=(1, 3)) & (q[:, 0, :, 0] != 0xFFFFFFFF)
+    assert same.mean() > 0.2
+    L = lin_np(z[:He, :We]).reshape(He // 2, 2, We // 2, 2)
+    dx = np.broadcast_to((L[:, :, :, 1:] - L[:, :, :, :1]) * 5.0, L.shape)
+    dy = np.broadcast_to((L[:, 1:, :, :] - L[:, :1, :, :]) * 5.0, L.shape)
+    want4 = srgb8_np(np.stack([dx, dy, np.zeros_like(dx), np.ones_like(dx)], -1)).transpose(0, 1, 2, 3, 4)
+    got4 = r4["rgba8"][:He, :We].reshape(He // 2, 2, We // 2, 2, 4)
+    m = np.broadcast_to(same[:, None, :, None], L.shape)
+    assert np.abs(want4[m].astype(np.int32) - got4[m].astype(np.int32)).max() <= 1
+    for mode in (5, 6):
+        ro = render_fn(debug=mode)
+        s_ = ro["stencil"].astype(np.float64) / 25.0
+        wanto = srgb8_np(np.stack([s_, 0.3 + s_, s_, np.full_like(s_, 0.1)], -1))
+        assert ro["stencil"].max() >= 2
+        assert np.abs(wanto.astype(np.int32) - ro["rgba8"].astype(np.int32)).max() <= 1
+
+
+def test_views_that_follow_from_the_side_buffers(micro_oracle):
+    check_views_from_side_buffers(lambda **kw: render(micro_oracle, W=128, H=72, pose=pose_matrix(0.5, -0.3, -2.0, 0.4, -0.15), **kw))
+
+
 def test_mip_view_levels_and_derivative_view(micro_oracle):
     m = render(micro_oracle, debug=2)
     cov = m["tri_id"] != 0xFFFFFFFF

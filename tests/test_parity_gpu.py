@@ -123,6 +123,20 @@ def test_mosaic_kernel_against_independent_restatement(gpu):
         assert d.max() <= 1, "%dx%d: mosaic differs by %d/255 at %d pixels" % (W, H, int(d.max()), int((d > 1).sum()))
 
 
+def test_views_that_follow_from_the_side_buffers_gpu(gpu):
+    """Depth, derivative, overdraw and overshading views of the HIP path against numpy restatements of debug.frag and
+    overVisRead.frag evaluated on the side buffers the same frame delivers."""
+    from test_oracle_properties import check_views_from_side_buffers
+    from vulkanrenderer_amd import abi, renderer
+    ctx, sc = gpu
+    W, H = 160, 90
+
+    def render_fn(debug):
+        u = renderer.make_uniforms(W, H, POSES["p1"], debug)
+        return sc.render(abi.make_params(W, H, u, shadow_size=256, debug=debug))
+    check_views_from_side_buffers(render_fn)
+
+
 def test_deferred_with_shadow_pass_flag(gpu, micro_oracle):
     """VKR_FRAME_SHADOW_PASS: the deferred frame is unchanged and the light's depth map equals the forward path's
     (and the oracle's)."""
