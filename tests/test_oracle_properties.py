@@ -157,6 +157,86 @@ def deferred_np(gn, ga, depth, u, W, H):
     return col
 
 
+def forward_np(gn, ga, depth, shadow_map, u, W, H):
+    """default.frag:82-104 predicted from the deferred G-buffer of the same pose (same visible surfaces; the
+    attachments hold the forward shader's own normal, metalness, albedo and roughness rounded to half precision):
+    N not re-normalised (:83), nDotH floored at 1e-4 inside D only (:35), brdf * 100 (:94), NdotL floored at 1e-4
+    (:96), 1/d^2, and the shadow term max(PCF, 0.1) (:99) from the light-space position of default.vert:46-50, 83 and
+    the frame's own shadow map (LINEAR compare sampler: four LESS_OR_EQUAL taps, then the bilinear blend)."""
+    PI = 3.14159265359
+    cam = np.array(u.sceneUniforms.camera, np.float64).reshape(4, 4).T
+    proj = np.array(u.sceneUniforms.projection, np.float64).reshape(4, 4).T
+    ys, xs = np.mgrid[0:H, 0:W]
+    clip = np.stack([(xs + 0.5) / W * 2 - 1, (ys + 0.5) / H * 2 - 1, depth.astype(np.float64), np.ones((H, W))], -1)
+    view = clip @ (np.linalg.inv(cam) @ np.linalg.inv(proj)).T
+    pos = view[..., :3] / view[..., 3:]
+    dot = lambda a, b: np.sum(a * b, -1, keepdims=True)
+    N = gn[..., :3].astype(np.float64)
+    metal, alb, rt = gn[..., 3:4].astype(np.float64), ga[..., :3].astype(np.float64), ga[..., 3:4].astype(np.float64)
+    lp = np.array(list(u.lightUniforms.lightPos)[:3])
+    Lv = lp - pos
+    d2 = dot(Lv, Lv)
+    Ld = Lv / np.sqrt(d2)
+    V = np.array(list(u.sceneUniforms.camPos)[:3]) - pos
+    V /= np.linalg.norm(V, axis=-1, keepdims=True)
+    Hv = V + Ld
+    Hv /= np.linalg.norm(Hv, axis=-1, keepdims=True)
+    r2 = (rt * rt) ** 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        nh = np.maximum(dot(N, Hv), 0.0001)
+        D = np.exp((nh * nh - 1) / (r2 * nh * nh)) / (0.001 + PI * r2 * nh ** 4)
+        f0 = (1 - metal) * 0.04 + metal * alb
+        F = f0 + (1 - f0) * (1 - dot(Hv, V)) ** 5
+        nh0 = np.maximum(0, dot(N, Hv))
+        G = np.minimum(1, np.minimum(2 * nh0 * np.maximum(0, dot(N, V)) / dot(V, Hv), 2 * nh0 * np.maximum(0, dot(N, Ld)) / dot(V, Hv)))
+        brdf = (alb / PI) * (1 - F) * (1 - metal) + D * F * G / (0.001 + 4 * np.maximum(dot(N, V), 0) * np.maximum(dot(N, Ld), 0))
+    ndl = np.maximum(dot(N, Ld), 0.0001)
+    # light-space position: biasMat * depthMVP * p, biasMat scaling xy by 0.5 and moving them by 0.5 w
+    M = np.array(u.depthMVPUniform.depthMVP, np.float64).reshape(4, 4).T
+    B = np.array([[0.5, 0, 0, 0.5], [0, 0.5, 0, 0.5], [0, 0, 1, 0], [0, 0, 0, 1]], np.float64)
+    ls = np.concatenate([pos, np.ones((H, W, 1))], -1) @ (B @ M).T
+    su, sv, ref = ls[..., 0] / ls[..., 3], ls[..., 1] / ls[..., 3], ls[..., 2] / ls[..., 3]
+    S = shadow_map.shape[0]
+    x, y = su * S - 0.5, sv * S - 0.5
+    x0, y0 = np.floor(x), np.floor(y)
+    fx, fy = x - x0, y - y0
+    ci = lambda a: np.clip(a, 0, S - 1).astype(int)
+    X0, X1, Y0, Y1 = ci(x0), ci(x0 + 1), ci(y0), ci(y0 + 1)
+    t = lambda yy, xx: (ref <= shadow_map[yy, xx]).astype(np.float64)
+    pcf = (t(Y0, X0) * (1 - fx) + t(Y0, X1) * fx) * (1 - fy) + (t(Y1, X0) * (1 - fx) + t(Y1, X1) * fx) * fy
+    shadow = np.maximum(pcf, 0.1)[..., None]
+    colour = np.array(list(u.lightUniforms.lightColour)[:3])
+    rgb = 0.03 * alb + ((brdf * 100 * colour * ndl) * shadow) / d2
+    return np.concatenate([rgb, np.ones((H, W, 1))], -1), pcf
+
+
+def check_forward_from_gbuffer(render_fn, W, H, u):
+    """render_fn(**mode) -> buffers.  The forward frame against forward_np over the deferred G-buffer of the same
+    pose.  The attachments are half precision and a pixel on a shadow edge can flip a tap, so: pixels away from
+    shadow edges, 99 % within 1/255 and none beyond 3/255."""
+    d = render_fn(deferred=True)
+    f = render_fn()
+    assert np.array_equal(d["tri_id"], f["tri_id"]) and np.array_equal(d["depth_bits"], f["depth_bits"])
+    gn = d["gbuf_normal"].view(np.float16).astype(np.float32)
+    ga = d["gbuf_albedo"].view(np.float16).astype(np.float32)
+    depth = f["depth_bits"].view(np.float32)
+    col, pcf = forward_np(gn, ga, depth, f["shadow_map"], u, W, H)
+    want = srgb8_np(col)
+    ok = (f["tri_id"] != 0xFFFFFFFF) & ((pcf == 0.0) | (pcf == 1.0))
+    assert ok.mean() > 0.3 and (pcf[ok] == 1.0).any() and (pcf[ok] == 0.0).any()   # lit and shadowed pixels both
+    e = np.abs(want[ok].astype(np.int32) - f["rgba8"][ok].astype(np.int32)).max(axis=-1)
+    assert (e <= 1).mean() >= 0.99 and e.max() <= 3, "forward differs: %.4f within 1/255, worst %d/255" % ((e <= 1).mean(), int(e.max()))
+
+
+def test_forward_pass_against_an_independent_restatement(micro_oracle):
+    from oracle import oracle
+    from vulkanrenderer_amd import abi
+    W, H = 128, 72
+    for pose in (IDENTITY, pose_matrix(0.5, -0.3, -2.0, 0.4, -0.15)):
+        u = oracle.make_uniforms(W, H, pose, 1)
+        check_forward_from_gbuffer(lambda **kw: micro_oracle.render(abi.make_params(W, H, u, shadow_size=256, **kw)), W, H, u)
+
+
 def srgb8_np(c):
     c = np.clip(c, 0.0, 1.0)
     rgb = np.where(c[..., :3] <= 0.0031308, c[..., :3] * 12.92, 1.055 * np.power(c[..., :3], 1 / 2.4) - 0.055)

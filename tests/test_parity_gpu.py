@@ -137,6 +137,18 @@ def test_views_that_follow_from_the_side_buffers_gpu(gpu):
     check_views_from_side_buffers(render_fn)
 
 
+def test_forward_kernel_against_independent_restatement(gpu):
+    """k_resolve_forward (BRDF x 100, floors, light-space position, PCF shadow term) against the numpy restatement of
+    default.frag evaluated over the deferred G-buffer and the shadow map the HIP path wrote for the same pose."""
+    from test_oracle_properties import check_forward_from_gbuffer
+    from vulkanrenderer_amd import abi, renderer
+    ctx, sc = gpu
+    W, H = 160, 90
+    for pose in (POSES["start"], POSES["p1"]):
+        u = renderer.make_uniforms(W, H, pose, 1)
+        check_forward_from_gbuffer(lambda **kw: sc.render(abi.make_params(W, H, u, shadow_size=256, **kw)), W, H, u)
+
+
 def test_deferred_with_shadow_pass_flag(gpu, micro_oracle):
     """VKR_FRAME_SHADOW_PASS: the deferred frame is unchanged and the light's depth map equals the forward path's
     (and the oracle's)."""
