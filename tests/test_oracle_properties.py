@@ -501,6 +501,22 @@ def check_views_from_side_buffers(render_fn):
     got4 = r4["rgba8"][:He, :We].reshape(He // 2, 2, We // 2, 2, 4)
     m = np.broadcast_to(same[:, None, :, None], L.shape)
     assert np.abs(want4[m].astype(np.int32) - got4[m].astype(np.int32)).max() <= 1
+    # mip view (debug.frag:19-38): the colour lies on the segment between the ramp entries of floor(lambda) and
+    # floor(lambda) + 1, and floor(lambda) is the integer mip_level buffer
+    ramp = np.array([[17, 119, 51], [136, 34, 85], [0, 114, 178], [204, 121, 167], [0, 158, 115], [213, 94, 0], [240, 228, 66]], np.float64) / 255.0
+    r2 = render_fn(debug=2)
+    lv = r2["mip_level"]
+    ok = lv != 0xFF
+    assert ok.mean() > 0.3 and len(np.unique(lv[ok])) >= 2
+    c = r2["rgba8"][ok][:, :3].astype(np.float64) / 255.0
+    lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    a, b = ramp[lv[ok] % 7], ramp[(lv[ok].astype(int) + 1) % 7]
+    tt = np.clip(np.sum((lin - a) * (b - a), -1) / np.sum((b - a) ** 2, -1), 0.0, 1.0)[:, None]
+    pred = srgb8_np(np.concatenate([a + tt * (b - a), np.ones((len(a), 1))], -1))
+    # within one 8-bit step, or - where the encoding is steepest, next to black - within 1.5e-3 in linear light
+    near = (np.abs(pred[:, :3].astype(np.int32) - r2["rgba8"][ok][:, :3].astype(np.int32)) <= 1) | (np.abs(a + tt * (b - a) - lin) < 1.5e-3)
+    assert near.all() and np.all(r2["rgba8"][ok][:, 3] == 255)
+    assert tt.min() < 0.2 and tt.max() > 0.8                                     # fractions of every size occur
     for mode in (5, 6):
         ro = render_fn(debug=mode)
         s_ = ro["stencil"].astype(np.float64) / 25.0
