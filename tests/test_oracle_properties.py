@@ -237,6 +237,50 @@ def test_forward_pass_against_an_independent_restatement(micro_oracle):
         check_forward_from_gbuffer(lambda **kw: micro_oracle.render(abi.make_params(W, H, u, shadow_size=256, **kw)), W, H, u)
 
 
+def check_flat_material_gbuffer(make_scene_renderer):
+    """A quad facing the camera with constant textures: the attachments must hold values that follow from the
+    conventions alone - base colour decoded from sRGB, roughness / metalness read as UNORM (main/main.cpp:3622), the
+    tangent-space normal mapped through 2x-1 and the TBN frame (gBufWrite.frag:16-27; the 10-bit quaternion keeps the
+    frame within 6e-3), the wall tilted so that the frame is not the identity.
+    make_scene_renderer(packed) -> render(params) -> buffers."""
+    from vulkanrenderer_amd import abi, scenes
+    from oracle import oracle
+
+    def const_tex(rgba, space):
+        return dict(rgba8=np.tile(np.array(rgba, np.uint8), (4, 4, 1)), space=space, channels=4)
+    textures = [const_tex((200, 100, 50, 255), 1), const_tex((128, 7, 9, 255), 0), const_tex((255, 3, 5, 255), 0),
+                const_tex((128, 128, 255, 255), 0), const_tex((255, 128, 128, 255), 0)]
+    du, dv = np.array([4.0, 0.0, -2.0]), np.array([0.0, 3.0, 0.0])
+    for nm_tex, nm_ts in ((3, (128 / 255 * 2 - 1, 128 / 255 * 2 - 1, 1.0)), (4, (1.0, 128 / 255 * 2 - 1, 128 / 255 * 2 - 1))):
+        mats = [(0, 1, 2, 0xFFFFFFFF, nm_tex, 0)]
+        mesh = scenes.grid_surface((-2, -1.5, -4), du, dv, 2, 2, (0, 0), (1, 0), (0, 1), 0)
+        render = make_scene_renderer(abi.PackedScene(textures, mats, [mesh]))
+        W, H = 96, 54
+        r = render(abi.make_params(W, H, oracle.make_uniforms(W, H, IDENTITY, 1), deferred=True))
+        hit = r["tri_id"] != 0xFFFFFFFF
+        assert hit.mean() > 0.15
+        ga = r["gbuf_albedo"].view(np.float16).astype(np.float64)[hit]
+        gn = r["gbuf_normal"].view(np.float16).astype(np.float64)[hit]
+        dec = lambda v: ((v / 255 + 0.055) / 1.055) ** 2.4
+        assert np.abs(ga[:, :3] - [dec(200), dec(100), dec(50)]).max() < 1e-3      # sRGB decoded
+        assert np.abs(ga[:, 3] - 128 / 255).max() < 1e-3 and np.abs(gn[:, 3] - 1.0).max() < 1e-3   # UNORM, .r
+        T = du / np.linalg.norm(du)
+        Nn = np.cross(du, dv); Nn /= np.linalg.norm(Nn)
+        Bn = np.cross(Nn, T)
+        ts = np.array(nm_ts); ts /= np.linalg.norm(ts)
+        want = ts[0] * T + ts[1] * Bn + ts[2] * Nn
+        assert np.abs(gn[:, :3] - want).max() < 1.5e-2, np.abs(gn[:, :3] - want).max()
+
+
+def test_flat_material_gbuffer_follows_the_conventions():
+    from oracle import oracle
+
+    def make(packed):
+        sc = oracle.OracleScene(packed)
+        return sc.render
+    check_flat_material_gbuffer(make)
+
+
 def srgb8_np(c):
     c = np.clip(c, 0.0, 1.0)
     rgb = np.where(c[..., :3] <= 0.0031308, c[..., :3] * 12.92, 1.055 * np.power(c[..., :3], 1 / 2.4) - 0.055)

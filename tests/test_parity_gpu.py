@@ -149,6 +149,23 @@ def test_forward_kernel_against_independent_restatement(gpu):
         check_forward_from_gbuffer(lambda **kw: sc.render(abi.make_params(W, H, u, shadow_size=256, **kw)), W, H, u)
 
 
+def test_flat_material_gbuffer_follows_the_conventions_gpu(gpu):
+    """The HIP path's G-buffer of a tilted quad with constant textures: sRGB decode of the base colour only, UNORM
+    roughness / metalness, tangent-space normal through the TBN frame (values derived from the conventions, no oracle)."""
+    from test_oracle_properties import check_flat_material_gbuffer
+    from vulkanrenderer_amd import renderer
+    ctx, _ = gpu
+    scenes_made = []
+
+    def make(packed):
+        sc = renderer.Scene(ctx, packed)
+        scenes_made.append(sc)
+        return sc.render
+    check_flat_material_gbuffer(make)
+    for sc in scenes_made:
+        sc.close()
+
+
 def test_deferred_with_shadow_pass_flag(gpu, micro_oracle):
     """VKR_FRAME_SHADOW_PASS: the deferred frame is unchanged and the light's depth map equals the forward path's
     (and the oracle's)."""
