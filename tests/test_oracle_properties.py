@@ -270,6 +270,18 @@ def check_flat_material_gbuffer(make_scene_renderer):
         ts = np.array(nm_ts); ts /= np.linalg.norm(ts)
         want = ts[0] * T + ts[1] * Bn + ts[2] * Nn
         assert np.abs(gn[:, :3] - want).max() < 1.5e-2, np.abs(gn[:, :3] - want).max()
+        # the depth attachment, unprojected the way deferredShading.frag:34-41 does it, lies on the quad's plane
+        u = oracle.make_uniforms(W, H, IDENTITY, 1)
+        cam = np.array(u.sceneUniforms.camera, np.float64).reshape(4, 4).T
+        proj = np.array(u.sceneUniforms.projection, np.float64).reshape(4, 4).T
+        ys, xs = np.mgrid[0:H, 0:W]
+        z = r["depth_bits"].view(np.float32).astype(np.float64)
+        clip = np.stack([(xs + 0.5) / W * 2 - 1, (ys + 0.5) / H * 2 - 1, z, np.ones((H, W))], -1)
+        view = clip @ (np.linalg.inv(cam) @ np.linalg.inv(proj)).T
+        pos = (view[..., :3] / view[..., 3:])[hit]
+        assert np.abs((pos - np.array([-2, -1.5, -4.0])) @ Nn).max() < 2e-3
+        st = np.stack([(pos - np.array([-2, -1.5, -4.0])) @ du / (du @ du), (pos - np.array([-2, -1.5, -4.0])) @ dv / (dv @ dv)], -1)
+        assert st.min() > -0.02 and st.max() < 1.02                               # and inside its outline
 
 
 def test_flat_material_gbuffer_follows_the_conventions():
