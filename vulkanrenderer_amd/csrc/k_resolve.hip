@@ -16,7 +16,7 @@
 struct Frag {
 	uint32_t prim;   // submission-order index
 	uint32_t tA;     // index into sc.tri (order A)
-	uint32_t i0, i1, i2;
+	const TriShade* ts; // the triangle's static shading record
 	TriPlanes pl;
 	float b[3];
 	float uv[2], d[4];
@@ -28,14 +28,11 @@ template <bool NEEDZ>
 __device__ __forceinline__ bool load_frag(const ResolveArgs& a, int px, int py, uint32_t tA, Frag& f)
 {
 	f.tA = tA;
-	f.i0 = a.sc.tri[3 * (size_t)tA + 0]; f.i1 = a.sc.tri[3 * (size_t)tA + 1]; f.i2 = a.sc.tri[3 * (size_t)tA + 2];
+	f.ts = a.sc.triShade + tA;
 	f.pl = a.planes[tA]; // every visible triangle went through k_setup, which stored its planes
 	vkr_bary_at(f.pl, px, py, f.b);
-	float2 t0 = make_float2(a.sc.uv[2 * (size_t)f.i0], a.sc.uv[2 * (size_t)f.i0 + 1]);
-	float2 t1 = make_float2(a.sc.uv[2 * (size_t)f.i1], a.sc.uv[2 * (size_t)f.i1 + 1]);
-	float2 t2 = make_float2(a.sc.uv[2 * (size_t)f.i2], a.sc.uv[2 * (size_t)f.i2 + 1]);
-	vkr_uv_derivs(f.pl, px, py, f.b, t0, t1, t2, f.uv, f.d);
-	f.mat = a.sc.triMat[tA];
+	vkr_uv_derivs(f.pl, px, py, f.b, f.ts->t0, f.ts->t1, f.ts->t2, f.uv, f.d);
+	f.mat = f.ts->mat;
 	return true;
 }
 
@@ -46,25 +43,14 @@ __device__ __forceinline__ void normalize3(float v[3])
 	v[0] *= inv; v[1] *= inv; v[2] *= inv;
 }
 
-__device__ __forceinline__ void load_tbn(const ResolveArgs& a, uint32_t v, float m[9])
-{
-	const float4 c0 = a.sc.tbn[3 * (size_t)v + 0], c1 = a.sc.tbn[3 * (size_t)v + 1], c2 = a.sc.tbn[3 * (size_t)v + 2];
-	m[0] = c0.x; m[1] = c0.y; m[2] = c0.z; m[3] = c0.w;
-	m[4] = c1.x; m[5] = c1.y; m[6] = c1.z; m[7] = c1.w;
-	m[8] = c2.x;
-}
 
 // normal = v2fTBN * normalize(texture(uNormalMap).rgb*2-1), TBN interpolated
 // per vertex (default.vert:57-81 decoded once per vertex at scene creation)
 __device__ __forceinline__ void shading_normal(const ResolveArgs& a, const Frag& f, const float nm[4], float n[3])
 {
-	float m0[9], m1[9], m2[9];
-	load_tbn(a, f.i0, m0);
-	load_tbn(a, f.i1, m1);
-	load_tbn(a, f.i2, m2);
 	float m[9];
 #pragma unroll
-	for (int i = 0; i < 9; i++) m[i] = vkr_interp(f.b, m0[i], m1[i], m2[i]);
+	for (int i = 0; i < 9; i++) m[i] = vkr_interp(f.b, f.ts->tbn[0][i], f.ts->tbn[1][i], f.ts->tbn[2][i]);
 	float t[3] = { nm[0] * 2.0f - 1.0f, nm[1] * 2.0f - 1.0f, nm[2] * 2.0f - 1.0f };
 	normalize3(t);
 #pragma unroll
@@ -79,19 +65,20 @@ struct MatSample { float nm[4], alb[4], metal, rough; };
 
 __device__ __forceinline__ void sample_material(const ResolveArgs& a, const Frag& f, const float* dec, MatSample& o)
 {
-	const MatInfo& mi = a.sc.mat[f.mat];
 	TexTaps tp;
 	float t[4];
-	if (mi.packNM != 0xffffffffu) {
-		// the four textures have one size: (normal.rgb, metalness.r) and (baseColor.rgb, roughness.r) per texel
-		const TexInfo& tn = a.sc.tex[mi.packNM];
-		vkr_make_taps(tn, f.uv[0], f.uv[1], f.d, tp);
-		vkr_fetch<15>(a.sc, tn, tp, dec, o.nm);
+	if (f.ts->levels) {
+		// the four textures have one size: (normal.rgb, metalness.r) and (baseColor.rgb, roughness.r) per texel;
+		// the chains are described by the triangle's record, nothing else is read before the texels
+		const uint32_t wh0 = f.ts->wh0;
+		vkr_make_taps_wh(wh0 & 0xffffu, wh0 >> 16, f.ts->levels, f.uv[0], f.uv[1], f.d, tp);
+		vkr_fetch_chain<15>(a.sc, f.ts->nmOff0, tp, nullptr, o.nm);
 		o.metal = o.nm[3];
-		vkr_fetch<15>(a.sc, a.sc.tex[mi.packAR], tp, dec, o.alb);
+		vkr_fetch_chain<15>(a.sc, f.ts->arOff0, tp, f.ts->srgbAR ? dec : nullptr, o.alb);
 		o.rough = o.alb[3];
 		return;
 	}
+	const MatInfo& mi = a.sc.mat[f.mat];
 	const TexInfo& tn = a.sc.tex[mi.tex[4]];
 	vkr_make_taps(tn, f.uv[0], f.uv[1], f.d, tp);
 	vkr_fetch<7>(a.sc, tn, tp, dec, o.nm);
@@ -224,7 +211,7 @@ __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 		shading_normal(a, f, ms.nm, N);
 #pragma unroll
 		for (int i = 0; i < 3; i++)
-			P[i] = vkr_interp(f.b, a.sc.pos[3 * (size_t)f.i0 + i], a.sc.pos[3 * (size_t)f.i1 + i], a.sc.pos[3 * (size_t)f.i2 + i]);
+			P[i] = vkr_interp(f.b, f.ts->pos[0][i], f.ts->pos[1][i], f.ts->pos[2][i]);
 		float Lv[3] = { a.lightPos[0] - P[0], a.lightPos[1] - P[1], a.lightPos[2] - P[2] };
 		float Vv[3] = { a.camPos[0] - P[0], a.camPos[1] - P[1], a.camPos[2] - P[2] };
 		float dist2 = vkr_dot3(Lv[0], Lv[1], Lv[2], Lv[0], Lv[1], Lv[2]);

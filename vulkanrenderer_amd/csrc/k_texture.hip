@@ -114,6 +114,43 @@ void vkr_launch_pack_chain(hipStream_t s, const uint32_t* rgb, const uint32_t* a
 }
 
 // ---------------------------------------------------------------------------
+// TriShade table: one record per triangle (submission order A).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tri_shade(SceneDev sc, TriShade* __restrict__ out)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= sc.nTri) return;
+	const uint32_t idx[3] = { sc.tri[3 * (size_t)t + 0], sc.tri[3 * (size_t)t + 1], sc.tri[3 * (size_t)t + 2] };
+	TriShade r;
+	r.t0 = make_float2(sc.uv[2 * (size_t)idx[0]], sc.uv[2 * (size_t)idx[0] + 1]);
+	r.t1 = make_float2(sc.uv[2 * (size_t)idx[1]], sc.uv[2 * (size_t)idx[1] + 1]);
+	r.t2 = make_float2(sc.uv[2 * (size_t)idx[2]], sc.uv[2 * (size_t)idx[2] + 1]);
+	r.mat = sc.triMat[t];
+	const MatInfo& mi = sc.mat[r.mat];
+	r.nmOff0 = r.arOff0 = 0u; r.wh0 = 0u; r.levels = 0; r.srgbAR = 0u;
+	if (mi.packNM != 0xffffffffu) {
+		const TexInfo& tn = sc.tex[mi.packNM];
+		const TexInfo& ta = sc.tex[mi.packAR];
+		r.nmOff0 = tn.offset[0]; r.arOff0 = ta.offset[0];
+		r.wh0 = tn.wh0; r.levels = tn.levels; r.srgbAR = (uint32_t)ta.srgb;
+	}
+	for (int v = 0; v < 3; v++) {
+		const float4 c0 = sc.tbn[3 * (size_t)idx[v] + 0], c1 = sc.tbn[3 * (size_t)idx[v] + 1], c2 = sc.tbn[3 * (size_t)idx[v] + 2];
+		r.tbn[v][0] = c0.x; r.tbn[v][1] = c0.y; r.tbn[v][2] = c0.z; r.tbn[v][3] = c0.w;
+		r.tbn[v][4] = c1.x; r.tbn[v][5] = c1.y; r.tbn[v][6] = c1.z; r.tbn[v][7] = c1.w;
+		r.tbn[v][8] = c2.x;
+		for (int k = 0; k < 3; k++) r.pos[v][k] = sc.pos[3 * (size_t)idx[v] + k];
+	}
+	out[t] = r;
+}
+
+void vkr_launch_tri_shade(hipStream_t s, const SceneDev& sc, TriShade* out)
+{
+	if (!sc.nTri) return;
+	hipLaunchKernelGGL(k_tri_shade, dim3((sc.nTri + 255) / 256), dim3(256), 0, s, sc, out);
+}
+
+// ---------------------------------------------------------------------------
 // AlphaAux table: one record per triangle (submission order A).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_alpha_aux(SceneDev sc, AlphaAux* __restrict__ out)

@@ -135,7 +135,7 @@ struct HostTex { uint32_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS], off[VKR_MAX_LEVE
 
 struct vkr_scene {
 	vkr_context* ctx = nullptr;
-	DevBuf pos, uv, tcomp, tbn, tri, triMat, orderB, tex, mat, texels, alphaTexels, alphaAux;
+	DevBuf pos, uv, tcomp, tbn, tri, triMat, orderB, tex, mat, texels, alphaTexels, alphaAux, triShade;
 	SceneDev dev;
 	std::vector<HostTex> htex;
 	uint64_t nTri = 0, nVert = 0, texelCount = 0;
@@ -573,7 +573,7 @@ extern "C" void vkr_scene_destroy(vkr_scene* s)
 		(void)hipStreamSynchronize(s->ctx->stream);
 		for (vkr_context* l : s->ctx->lanes) (void)hipStreamSynchronize(l->stream);
 	}
-	DevBuf* bufs[] = { &s->pos, &s->uv, &s->tcomp, &s->tbn, &s->tri, &s->triMat, &s->orderB, &s->tex, &s->mat, &s->texels, &s->alphaTexels, &s->alphaAux };
+	DevBuf* bufs[] = { &s->pos, &s->uv, &s->tcomp, &s->tbn, &s->tri, &s->triMat, &s->orderB, &s->tex, &s->mat, &s->texels, &s->alphaTexels, &s->alphaAux, &s->triShade };
 	for (DevBuf* b : bufs) b->release();
 	delete s;
 }
@@ -801,6 +801,9 @@ static int scene_create_impl(vkr_context* c, const vkr_scene_desc* d, vkr_scene*
 	dv.nTex = (uint32_t)s->htex.size(); dv.nMat = d->materialCount;
 	dv.alphaAux = s->alphaAux.as<AlphaAux>();
 	vkr_launch_alpha_aux(c->stream, dv, s->alphaAux.as<AlphaAux>());
+	if ((rc = s->triShade.ensure(nTri ? nTri * sizeof(TriShade) : sizeof(TriShade)))) return fail(rc);
+	dv.triShade = s->triShade.as<TriShade>();
+	vkr_launch_tri_shade(c->stream, dv, s->triShade.as<TriShade>());
 	{
 		hipError_t e = hipStreamSynchronize(c->stream);
 		if (e != hipSuccess) return fail(set_error(VKR_E_DEVICE, "mip generation: %s", hipGetErrorString(e)));

@@ -66,6 +66,21 @@ struct SubTri {
 #define VKR_ST_ALPHA 1u
 #define VKR_ST_FRONT 2u
 
+// Per triangle (submission order A), built once per scene: everything the shading kernels need that does not change
+// from frame to frame, so that a pixel's chain of dependent loads is visibility key -> (interpolation planes, this
+// record) -> texels, instead of key -> indices -> vertices / material -> texture description -> level offset -> texels.
+struct alignas(16) TriShade {
+	float2 t0, t1, t2;        // texture coordinates of the three vertices
+	uint32_t nmOff0, arOff0;  // first texel of the repacked chains (normal.rgb, metalness.r) and (baseColor.rgb, roughness.r)
+	uint32_t wh0;             // their size, width | height << 16
+	int32_t levels;           // 0: the material has no repacked chains (the general path shades)
+	uint32_t srgbAR;          // the base-colour bytes are sRGB
+	uint32_t mat;
+	float tbn[3][9];          // decoded TBN matrix of the three vertices (default.vert:57-81), column-major
+	float pos[3][3];          // world positions of the three vertices (the forward shader interpolates them)
+};
+static_assert(sizeof(TriShade) == 192, "TriShade is twelve 16-byte loads");
+
 struct SceneDev {
 	const float* pos;        // 3 per vertex
 	const float* uv;         // 2 per vertex
@@ -79,6 +94,7 @@ struct SceneDev {
 	const uint32_t* texels;  // texel pool
 	const uint8_t* alphaTexels; // alpha bytes of the textures an alpha test samples, same level layout per chain
 	const struct AlphaAux* alphaAux; // per triangle (order A): what an alpha test needs besides the interpolation planes
+	const TriShade* triShade;        // per triangle (order A)
 	const float* srgbDecode; // 256
 	const float* srgbThresh; // 255
 	uint32_t nTri, nTriOpaque, nVert, nTex, nMat;
@@ -472,6 +488,24 @@ __device__ __forceinline__ void vkr_fetch(const SceneDev& sc, const TexInfo& t, 
 	const uint32_t* b0 = sc.texels + t.offset[tp.lv];
 	if (tp.fr == 0.0f) { vkr_bilinear_taps<MASK>(b0, tp.t0, dec, out); return; }
 	const uint32_t* b1 = sc.texels + t.offset[tp.lv + 1];
+	float a[4], b[4];
+	vkr_bilinear_taps<MASK>(b0, tp.t0, dec, a);
+	vkr_bilinear_taps<MASK>(b1, tp.t1, dec, b);
+#pragma unroll
+	for (int c = 0; c < 4; c++)
+		if (MASK & (1 << c)) out[c] = vkr_lerp(a[c], b[c], tp.fr);
+}
+
+// vkr_fetch for a chain described by (first texel, size): the level offsets are recomputed instead of read from the
+// texture table, which takes a memory round trip out of the pixel's dependent chain.  Same texels, same arithmetic.
+template <int MASK>
+__device__ __forceinline__ void vkr_fetch_chain(const SceneDev& sc, uint32_t off0, const TexTaps& tp, const float* dec, float out[4])
+{
+	const uint32_t o0 = vkr_level_offset(off0, tp.w0, tp.h0, tp.lv);
+	const uint32_t* b0 = sc.texels + o0;
+	if (tp.fr == 0.0f) { vkr_bilinear_taps<MASK>(b0, tp.t0, dec, out); return; }
+	uint32_t w = tp.w0 >> tp.lv, h = tp.h0 >> tp.lv;
+	const uint32_t* b1 = sc.texels + o0 + (w ? w : 1u) * (h ? h : 1u);
 	float a[4], b[4];
 	vkr_bilinear_taps<MASK>(b0, tp.t0, dec, a);
 	vkr_bilinear_taps<MASK>(b1, tp.t1, dec, b);

@@ -134,6 +134,7 @@ void vkr_launch_mip_level(hipStream_t s, uint32_t* texels, uint32_t srcOff, uint
                           uint32_t dw, uint32_t dh, int srgb, const float* srgbDecode, const float* srgbThresh);
 void vkr_launch_extract_alpha(hipStream_t s, const uint32_t* texels, uint8_t* out, uint32_t n);
 void vkr_launch_alpha_aux(hipStream_t s, const SceneDev& sc, AlphaAux* out);
+void vkr_launch_tri_shade(hipStream_t s, const SceneDev& sc, TriShade* out);
 void vkr_launch_pack_chain(hipStream_t s, const uint32_t* rgb, const uint32_t* a, uint32_t* out, uint32_t n);
 void vkr_launch_tbn_table(hipStream_t s, const uint32_t* tcomp, float4* out, uint32_t nVert);
 void vkr_launch_fill_u32(hipStream_t s, uint32_t* dst, uint32_t value, size_t n);
