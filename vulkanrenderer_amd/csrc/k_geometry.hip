@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 		out[0] = make_uint4(vloc[0], vloc[1], vloc[2], vloc[3]);
 		if (nt > 4) out[1] = make_uint4(vloc[4], vloc[5], vloc[6], vloc[7]);
 	}
-	// records that touch many tiles: queued for k_count_big / k_bin_fill_big (one wavefront per record; they come in
+	// records that touch many tiles: queued for k_count_big / the first workgroups of k_bin_fill (one wavefront per record; they come in
 	// runs - the near-field triangles of a mesh - and would otherwise pile up in a few wavefronts)
 	unsigned long long bmask = __ballot(nt > 8);
 	if (bmask) {
@@ -428,9 +428,16 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 
 // One thread per record slot; a record that touches more than 8 tiles is
 // spread over the whole wavefront.
+#define BIG_FILL_BLOCKS 256u // workgroups of k_bin_fill that take the many-tile records
+
+__device__ __forceinline__ void bin_fill_big(const BinFillArgs& a);
+
+// One launch fills both kinds of entries: the first BIG_FILL_BLOCKS workgroups take the records that touch more than
+// 8 tiles (cursor atomics, behind the others' entries), the rest one thread per record slot.
 __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 {
-	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (blockIdx.x < BIG_FILL_BLOCKS) { bin_fill_big(a); return; }
+	const uint32_t r = (blockIdx.x - BIG_FILL_BLOCKS) * blockDim.x + threadIdx.x;
 	const uint32_t n = min(a.baseCount + *a.recCount, a.recCap);
 	bool has = r < n;
 	uint32_t tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0, key = 0;
@@ -463,10 +470,10 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinFillArgs a)
 
 // The records that touch more than 8 tiles, one wavefront per record (lanes over its tiles); their entries go behind
 // the others' in each tile's bin, positions from a cursor.
-__global__ __launch_bounds__(256) void k_bin_fill_big(BinFillArgs a)
+__device__ __forceinline__ void bin_fill_big(const BinFillArgs& a)
 {
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (BIG_FILL_BLOCKS * blockDim.x) >> 6;
 	const uint32_t n = min(*a.bigCount, a.recCap);
 	for (uint32_t q = wave; q < n; q += nWaves) {
 		const uint32_t r = a.bigQueue[q];
@@ -510,6 +517,5 @@ void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t*
 void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs)
 {
 	if (!maxRecs) return;
-	hipLaunchKernelGGL(k_bin_fill, dim3((maxRecs + 255) / 256), dim3(256), 0, s, a);
-	hipLaunchKernelGGL(k_bin_fill_big, dim3(256), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_bin_fill, dim3(BIG_FILL_BLOCKS + (maxRecs + 255) / 256), dim3(256), 0, s, a);
 }
