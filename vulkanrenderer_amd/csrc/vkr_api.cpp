@@ -129,6 +129,10 @@ struct vkr_context {
 	std::vector<vkr_context*> lanes;
 	vkr_context* parent = nullptr;
 	uint32_t nextLane = 0;
+	// forward path: the light's depth pass runs on a helper context (stream + geometry scratch + the shadow map of its
+	// own) beside the camera's geometry and raster passes; the two streams fork and join through these events
+	vkr_context* shadowHelper = nullptr;
+	hipEvent_t evFork = nullptr, evJoin = nullptr;
 };
 
 struct HostTex { uint32_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS], off[VKR_MAX_LEVELS]; int levels; int srgb; };
@@ -459,6 +463,9 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 	if (!c) return;
 	for (vkr_context* l : c->lanes) vkr_context_destroy(l);
 	c->lanes.clear();
+	if (c->shadowHelper) { c->shadowHelper->hStatus = nullptr; vkr_context_destroy(c->shadowHelper); c->shadowHelper = nullptr; }
+	if (c->evFork) (void)hipEventDestroy(c->evFork);
+	if (c->evJoin) (void)hipEventDestroy(c->evJoin);
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	DevBuf* bufs[] = { &c->clip, &c->planes, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->bigQueue, &c->counters, &c->tileCount, &c->tileCountA, &c->tileCountBig, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
@@ -517,7 +524,8 @@ extern "C" int vkr_profile_enable(vkr_context* c, int on)
 {
 	if (!c) return set_error(VKR_E_INVALID, "NULL context");
 	c->profiling = on;
-	for (vkr_context* l : c->lanes) l->profiling = on;
+	if (c->shadowHelper) c->shadowHelper->profiling = on;
+	for (vkr_context* l : c->lanes) { l->profiling = on; if (l->shadowHelper) l->shadowHelper->profiling = on; }
 	return VKR_OK;
 }
 static int profile_reset_impl(vkr_context* c)
@@ -527,6 +535,10 @@ static int profile_reset_impl(vkr_context* c)
 	HIP_CHECK(hipStreamSynchronize(c->stream));
 	drain_timers(c);
 	for (int i = 0; i < ST_COUNT; i++) { c->stageMs[i] = 0; c->stageLaunches[i] = 0; }
+	if (c->shadowHelper) {
+		int rc = profile_reset_impl(c->shadowHelper);
+		if (rc) return rc;
+	}
 	for (vkr_context* l : c->lanes) {
 		int rc = profile_reset_impl(l);
 		if (rc) return rc;
@@ -543,6 +555,12 @@ static int profile_get_impl(vkr_context* c, int stage, double* ms, uint64_t* lau
 	drain_timers(c);
 	double total = c->stageMs[stage];
 	uint64_t n = c->stageLaunches[stage];
+	if (c->shadowHelper) {
+		double lm = 0.0; uint64_t ln = 0;
+		int rc = profile_get_impl(c->shadowHelper, stage, &lm, &ln);
+		if (rc) return rc;
+		total += lm; n += ln;
+	}
 	for (vkr_context* l : c->lanes) {
 		double lm = 0.0; uint64_t ln = 0;
 		int rc = profile_get_impl(l, stage, &lm, &ln);
@@ -978,7 +996,25 @@ static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 	const vkr_uniforms& u = fp.uniforms;
 	const uint32_t S = fp.shadow_size ? fp.shadow_size : 2048;
 	int rc;
-	if ((rc = run_shadow(c, s, fp, statusSlot))) return rc;
+	// The light's pass and the camera's geometry + raster passes do not depend on each other: the first runs on the
+	// helper's stream, forked after everything queued here so far (the previous frame's resolve read the helper's map)
+	// and joined in front of the resolve.
+	vkr_context* h = c->shadowHelper;
+	if (!h) {
+		if ((rc = vkr_context_create(c->device, &h))) return rc;
+		h->parent = c;
+		c->shadowHelper = h;
+		HIP_CHECK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+		HIP_CHECK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+	}
+	h->profiling = c->profiling; h->capScale = c->capScale; h->binFloor = c->binFloor;
+	HIP_CHECK(hipEventRecord(c->evFork, c->stream));
+	HIP_CHECK(hipStreamWaitEvent(h->stream, c->evFork, 0));
+	h->hStatus = c->hStatus; // the pass status lands in this context's slots, where vkr_wait looks for it
+	rc = run_shadow(h, s, fp, statusSlot);
+	h->hStatus = nullptr;
+	if (rc) return rc;
+	HIP_CHECK(hipEventRecord(c->evJoin, h->stream));
 	const size_t n = (size_t)(view.x1 - view.x0) * (view.y1 - view.y0);
 	if ((rc = c->vis.ensure(n * 8))) return rc;
 	if ((rc = c->depth.ensure(n * 4))) return rc;
@@ -997,12 +1033,13 @@ static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 			r.alphaPass = s->anyAlphaTest ? 1 : 0;
 			vkr_launch_raster(c->stream, RASTER_VIS, r);
 		}
+		HIP_CHECK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
 		StageTimer t(c, ST_RESOLVE_FORWARD);
 		ResolveArgs a;
 		memset(&a, 0, sizeof a);
 		a.sc = s->dev; a.view = view; a.clip = c->clip.as<float4>(); a.planes = c->planes.as<TriPlanes>(); a.vis = c->vis.as<unsigned long long>();
 		a.depth = c->depth.as<float>(); a.triId = c->triId.as<uint32_t>(); a.colour = colourDst;
-		a.shadow = c->shadow.as<float>(); a.shadowSize = S;
+		a.shadow = h->shadow.as<float>(); a.shadowSize = S;
 		static const float biasMat[16] = { 0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 1.0f, 0, 0.5f, 0.5f, 0, 1.0f }; // default.vert:46-50
 		mat4_mul(biasMat, u.depthMVPUniform.depthMVP, a.lightMat.m);
 		memcpy(a.lightPos, u.lightUniforms.lightPos, 16); memcpy(a.lightColour, u.lightUniforms.lightColour, 16);
@@ -1013,7 +1050,7 @@ static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 		StageTimer t(c, ST_COPY_OUT);
 		if ((rc = copy_out(c, out->tri_id, c->triId.p, n * 4))) return rc;
 		if ((rc = copy_out(c, out->depth_bits, c->depth.p, n * 4))) return rc;
-		if ((rc = copy_out(c, out->shadow_map, c->shadow.p, (size_t)S * S * 4))) return rc;
+		if ((rc = copy_out(c, out->shadow_map, h->shadow.p, (size_t)S * S * 4))) return rc;
 	}
 	return VKR_OK;
 }
