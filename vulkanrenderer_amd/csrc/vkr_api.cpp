@@ -990,15 +990,12 @@ static int run_shadow(vkr_context* c, const vkr_scene* s, const vkr_frame_params
 	return VKR_OK;
 }
 
-static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_params& fp, const ViewDev& view, uint32_t* colourDst,
-                       uint32_t statusSlot, const vkr_frame_out* out, bool writeSide)
+// The light's pass does not depend on the camera's passes of the same frame: it runs on the helper context's stream,
+// forked after everything queued on this context so far (the previous frame's shading read the helper's map); the
+// caller joins (join_shadow) in front of whatever reads the map.
+static int run_shadow_beside(vkr_context* c, const vkr_scene* s, const vkr_frame_params& fp, uint32_t statusSlot)
 {
-	const vkr_uniforms& u = fp.uniforms;
-	const uint32_t S = fp.shadow_size ? fp.shadow_size : 2048;
 	int rc;
-	// The light's pass and the camera's geometry + raster passes do not depend on each other: the first runs on the
-	// helper's stream, forked after everything queued here so far (the previous frame's resolve read the helper's map)
-	// and joined in front of the resolve.
 	vkr_context* h = c->shadowHelper;
 	if (!h) {
 		if ((rc = vkr_context_create(c->device, &h))) return rc;
@@ -1015,6 +1012,23 @@ static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 	h->hStatus = nullptr;
 	if (rc) return rc;
 	HIP_CHECK(hipEventRecord(c->evJoin, h->stream));
+	return VKR_OK;
+}
+
+static int join_shadow(vkr_context* c)
+{
+	HIP_CHECK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
+	return VKR_OK;
+}
+
+static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_params& fp, const ViewDev& view, uint32_t* colourDst,
+                       uint32_t statusSlot, const vkr_frame_out* out, bool writeSide)
+{
+	const vkr_uniforms& u = fp.uniforms;
+	const uint32_t S = fp.shadow_size ? fp.shadow_size : 2048;
+	int rc;
+	if ((rc = run_shadow_beside(c, s, fp, statusSlot))) return rc;
+	vkr_context* h = c->shadowHelper;
 	const size_t n = (size_t)(view.x1 - view.x0) * (view.y1 - view.y0);
 	if ((rc = c->vis.ensure(n * 8))) return rc;
 	if ((rc = c->depth.ensure(n * 4))) return rc;
@@ -1033,7 +1047,7 @@ static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 			r.alphaPass = s->anyAlphaTest ? 1 : 0;
 			vkr_launch_raster(c->stream, RASTER_VIS, r);
 		}
-		HIP_CHECK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
+		if ((rc = join_shadow(c))) return rc;
 		StageTimer t(c, ST_RESOLVE_FORWARD);
 		ResolveArgs a;
 		memset(&a, 0, sizeof a);
@@ -1101,7 +1115,7 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 		if (fp.flags & VKR_FRAME_SHADOW_PASS) {
 			// not a reference combination (its deferred path has no shadow pass): the map is rendered, handed out
 			// if asked for, and not sampled
-			if ((rc = run_shadow(c, s, fp, statusSlot + 1))) return rc;
+			if ((rc = run_shadow_beside(c, s, fp, statusSlot + 1))) return rc;
 			*nPasses = 2;
 		}
 		if ((rc = run_geometry(c, s, g, statusSlot))) return rc;
@@ -1150,11 +1164,12 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 			StageTimer t(c, ST_DEFERRED_LIGHT);
 			vkr_launch_deferred_light(c->stream, l);
 		}
+		if ((fp.flags & VKR_FRAME_SHADOW_PASS) && (rc = join_shadow(c))) return rc;
 		StageTimer t(c, ST_COPY_OUT);
 		if ((rc = copy_out(c, rgbaCopy, c->colour.p, n * 4)) || (rc = copy_out(c, out.tri_id, c->triId.p, n * 4)) ||
 		    (rc = copy_out(c, out.depth_bits, c->depth.p, n * 4)) || (rc = copy_out(c, out.gbuf_normal, c->gN.p, n * 8)) ||
 		    (rc = copy_out(c, out.gbuf_albedo, c->gA.p, n * 8))) return rc;
-		if ((fp.flags & VKR_FRAME_SHADOW_PASS) && (rc = copy_out(c, out.shadow_map, c->shadow.p, (size_t)S * S * 4))) return rc;
+		if ((fp.flags & VKR_FRAME_SHADOW_PASS) && (rc = copy_out(c, out.shadow_map, c->shadowHelper->shadow.p, (size_t)S * S * 4))) return rc;
 	} else if (!fp.mosaicEffect && dbg == 1) {
 		// ---- forward + shadow map (main/main.cpp:3948-4079)
 		if ((rc = run_forward(c, s, fp, view, colourDst, statusSlot, &out, true))) return rc;
