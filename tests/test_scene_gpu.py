@@ -468,3 +468,20 @@ def test_bin_overflow_is_rerendered(micro):
         assert set(np.unique(r).tolist()) <= {0, 1, 2, 3}   # the nearest quad (first four triangles) everywhere
     finally:
         sc.close(); ctx.close()
+    # forward path, fresh context: the light's pass (on the helper stream) and the camera's pass both outgrow their first
+    # bins; the re-rendered frame equals the same frame rendered once the buffers have grown
+    pos2 = pos.copy(); pos2[:, 2] -= 28.0   # in front of the light as well (it looks down -z from z = -12)
+    mesh2 = dict(mesh, positions=pos2)
+    ctx = renderer.Context(0)
+    sc = renderer.Scene(ctx, abi.PackedScene(micro.textures, micro.materials, [mesh2]))
+    try:
+        W, H = 1920, 1080
+        p = abi.make_params(W, H, renderer.make_uniforms(W, H, IDENTITY, 1), shadow_size=2048)
+        first = sc.render(p, want=("rgba8", "tri_id", "shadow_map"))
+        again = sc.render(p, want=("rgba8", "tri_id", "shadow_map"))
+        for k in first:
+            assert np.array_equal(first[k], again[k]), k
+        assert set(np.unique(first["tri_id"]).tolist()) <= {0, 1, 2, 3}
+        assert (first["shadow_map"] < 1.0).mean() > 0.5      # the quads fill most of the light's view
+    finally:
+        sc.close(); ctx.close()
