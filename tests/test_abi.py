@@ -46,7 +46,7 @@ def test_null_arguments_fail_cleanly():
     assert L.vkr_scene_stats(None, None, None, None) != 0
     L.vkr_context_destroy(None)
     L.vkr_scene_destroy(None)
-    assert L.vkr_stage_count() >= 10 and L.vkr_stage_name(0) == b"k_xform"
+    assert L.vkr_stage_count() >= 10 and L.vkr_stage_name(0) == b"k_setup"
 
 
 def test_no_device_is_an_error_not_a_fallback():

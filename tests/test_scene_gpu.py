@@ -272,7 +272,7 @@ def test_frames_in_flight_on_lanes(micro):
         for ref, (img, tid) in zip(single, outs):
             assert np.array_equal(ref["rgba8"], img) and np.array_equal(ref["tri_id"], tid)
     rep = c.profile_report()
-    assert rep["k_xform"][1] >= 2 * len(jobs)  # stage timers of every lane are summed
+    assert rep["k_setup"][1] >= 2 * len(jobs)  # stage timers of every lane are summed
     c.set_frames_in_flight(1)
     again = sc.render(jobs[0], want=("rgba8",))["rgba8"]
     assert np.array_equal(again, single[0]["rgba8"])

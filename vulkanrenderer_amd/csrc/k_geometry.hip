@@ -1,5 +1,5 @@
-// k_geometry.hip — vertex transform, triangle setup (clip, cull, snap, depth
-// plane), and screen-tile binning (count -> scan -> fill).
+// k_geometry.hip — vertex transform (inside triangle setup), triangle setup (clip,
+// cull, snap, depth plane), and screen-tile binning (count -> scan -> fill).
 //
 // Replaces, for every draw of a pass, the vertex shader's
 // gl_Position = projCam * vec4(iPosition,1) (default.vert:85, gBufWrite.vert:70,
@@ -8,18 +8,6 @@
 // configured at main/main.cpp:2274-2305 (and :3105-3115 for the shadow pass).
 // Compiled with -ffp-contract=off: the arithmetic order defines coverage.
 #include "vkr_kernels.h"
-
-// ---------------------------------------------------------------------------
-// Also zeroes the pass's counters (the kernels after it accumulate into them), which saves four fill launches.
-__global__ __launch_bounds__(256) void k_xform(const float* __restrict__ pos, float4* __restrict__ clip, uint32_t nVert, Mat4 M, ZeroArgs zr)
-{
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	for (uint32_t i = v; i < zr.nTiles; i += gridDim.x * blockDim.x) { zr.tiles0[i] = 0u; zr.tiles1[i] = 0u; zr.tiles2[i] = 0u; }
-	if (v < 16u) zr.counters[v] = 0u;
-	if (v >= nVert) return;
-	float x = pos[3 * (size_t)v + 0], y = pos[3 * (size_t)v + 1], z = pos[3 * (size_t)v + 2];
-	clip[v] = vkr_xform(M, x, y, z);
-}
 
 // ---------------------------------------------------------------------------
 struct ClipV { double x, y, z, w; };
@@ -188,7 +176,10 @@ struct TriFront {
 __device__ __forceinline__ bool tri_front(const SetupArgs& a, uint32_t t, TriFront& f)
 {
 	const uint32_t i0 = a.sc.tri[3 * (size_t)t + 0], i1 = a.sc.tri[3 * (size_t)t + 1], i2 = a.sc.tri[3 * (size_t)t + 2];
-	const float4 c0 = a.clip[i0], c1 = a.clip[i1], c2 = a.clip[i2];
+	// the vertex stage: every triangle transforms its own three vertices (the same arithmetic per vertex whoever does it)
+	const float4 c0 = vkr_xform(a.M, a.sc.pos[3 * (size_t)i0], a.sc.pos[3 * (size_t)i0 + 1], a.sc.pos[3 * (size_t)i0 + 2]);
+	const float4 c1 = vkr_xform(a.M, a.sc.pos[3 * (size_t)i1], a.sc.pos[3 * (size_t)i1 + 1], a.sc.pos[3 * (size_t)i1 + 2]);
+	const float4 c2 = vkr_xform(a.M, a.sc.pos[3 * (size_t)i2], a.sc.pos[3 * (size_t)i2 + 1], a.sc.pos[3 * (size_t)i2 + 2]);
 	f.c0 = c0; f.c1 = c1; f.c2 = c2;
 	bool ok = true;
 	// NaN anywhere -> drop
@@ -233,6 +224,9 @@ __device__ __forceinline__ bool tri_front(const SetupArgs& a, uint32_t t, TriFro
 __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 {
 	__shared__ uint32_t sTag[SETUP_TABLE], sCnt[SETUP_TABLE], sBase[SETUP_TABLE];
+	// the next pass's counters (the other set of the pair; nothing in flight uses it) are zeroed here, so that no pass
+	// needs a fill launch of its own
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.zeroWords; i += gridDim.x * blockDim.x) a.zeroBase[i] = 0u;
 	for (uint32_t h = threadIdx.x; h < SETUP_TABLE; h += blockDim.x) { sTag[h] = 0xffffffffu; sCnt[h] = 0u; }
 	__syncthreads();
 	const uint32_t t = a.first + blockIdx.x * blockDim.x + threadIdx.x;
@@ -493,16 +487,11 @@ __device__ __forceinline__ void bin_fill_big(const BinFillArgs& a)
 }
 
 // ---------------------------------------------------------------------------
-void vkr_launch_xform(hipStream_t s, const float* pos, float4* clip, uint32_t nVert, const Mat4& M, const ZeroArgs& z)
-{
-	// at least one workgroup, so that the counters are zeroed for an empty scene too
-	hipLaunchKernelGGL(k_xform, dim3(nVert ? (nVert + 255) / 256 : 1), dim3(256), 0, s, pos, clip, nVert, M, z);
-}
-
 void vkr_launch_setup(hipStream_t s, const SetupArgs& a)
 {
+	// at least one workgroup: it also zeroes the next pass's counters
+	hipLaunchKernelGGL(k_setup, dim3(a.count ? (a.count + 255) / 256 : 1), dim3(256), 0, s, a);
 	if (!a.count) return;
-	hipLaunchKernelGGL(k_setup, dim3((a.count + 255) / 256), dim3(256), 0, s, a);
 	// few triangles need the clipper; a fixed grid strides over however many were queued
 	hipLaunchKernelGGL(k_setup_clip, dim3(512), dim3(64), 0, s, a);
 	hipLaunchKernelGGL(k_count_big, dim3(256), dim3(256), 0, s, a);

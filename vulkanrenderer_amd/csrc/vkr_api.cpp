@@ -62,12 +62,12 @@ template <class F> static int guarded(const char* fn, F&& body) noexcept
 // stages
 // ---------------------------------------------------------------------------
 enum Stage {
-	ST_XFORM, ST_SETUP, ST_BIN_SCAN, ST_BIN_FILL, ST_RASTER_VIS, ST_RASTER_SHADOW, ST_RASTER_COUNT, ST_SORT_BINS,
+	ST_SETUP, ST_BIN_SCAN, ST_BIN_FILL, ST_RASTER_VIS, ST_RASTER_SHADOW, ST_RASTER_COUNT, ST_SORT_BINS,
 	ST_OVERSHADE, ST_RESOLVE_GBUF, ST_RESOLVE_FORWARD, ST_RESOLVE_DEBUG, ST_DEFERRED_LIGHT, ST_OVERVIS_COLOUR, ST_MOSAIC,
 	ST_COPY_OUT, ST_RESOLVE_LIGHT, ST_COUNT
 };
 static const char* kStageNames[ST_COUNT] = {
-	"k_xform", "k_setup", "k_scan_tiles", "k_bin_fill", "k_raster_vis", "k_raster_shadow", "k_raster_count", "sort_bins",
+	"k_setup", "k_scan_tiles", "k_bin_fill", "k_raster_vis", "k_raster_shadow", "k_raster_count", "sort_bins",
 	"k_overshade", "k_resolve_gbuf", "k_resolve_forward", "k_resolve_debug", "k_deferred_light", "k_overvis_colour",
 	"k_mosaic", "copy_out", "k_resolve_light"
 };
@@ -108,7 +108,16 @@ struct vkr_context {
 	float* dThresh = nullptr; // 255
 	float hDecode[256], hThresh[255];
 	// geometry scratch
-	DevBuf clip, planes, recs, recTiles, recLocal, clipQueue, bigQueue, counters, tileCount, tileCountA, tileCountBig, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
+	DevBuf clip, planes, recs, recTiles, recLocal, clipQueue, bigQueue, zeroSets, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
+	// counters + per-tile counts of a pass, twice: a pass uses one set while its k_setup zeroes the other for the next pass
+	// layout of a set: 16 counters ([0] recCount, [1] overflow, [2] alpha tile count, [3] clip queue length,
+	// [4] big-record queue length, [5] deep alpha tile count), then tileCount, tileCountA, tileCountBig (zeroCapTiles each)
+	uint32_t zeroCapTiles = 0; int zset = 0;
+	uint32_t* zs(int which) const { return (uint32_t*)zeroSets.p + (size_t)which * (16 + 3 * (size_t)zeroCapTiles); }
+	uint32_t* counters() const { return zs(zset); }
+	uint32_t* tileCount() const { return zs(zset) + 16; }
+	uint32_t* tileCountA() const { return zs(zset) + 16 + zeroCapTiles; }
+	uint32_t* tileCountBig() const { return zs(zset) + 16 + 2 * (size_t)zeroCapTiles; }
 	uint32_t recCap = 0, binCap = 0;
 	double capScale = 1.0;
 	uint64_t binFloor = 0; // bin entries a pass has been seen to need (from an overflowed attempt)
@@ -468,7 +477,7 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 	if (c->evJoin) (void)hipEventDestroy(c->evJoin);
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf* bufs[] = { &c->clip, &c->planes, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->bigQueue, &c->counters, &c->tileCount, &c->tileCountA, &c->tileCountBig, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
+	DevBuf* bufs[] = { &c->clip, &c->planes, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->bigQueue, &c->zeroSets, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
 		&c->binKeys, &c->binList2, &c->binKeys2, &c->sortTemp, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
 		&c->colour2, &c->stencil, &c->mip, &c->shadow };
 	for (DevBuf* b : bufs) b->release();
@@ -892,54 +901,53 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	const uint32_t recCap = (uint32_t)std::min<double>(4.0e9, (double)g.count + ((double)g.count * 0.25 + 4096.0) * c->capScale);
 	const uint32_t binCap = (uint32_t)std::min<double>(4.0e9, std::max<double>(((double)recCap * 3.0 + nTiles) * c->capScale, (double)c->binFloor));
 	int rc;
-	if ((rc = c->clip.ensure((size_t)s->dev.nVert * sizeof(float4)))) return rc;
 	if ((rc = c->planes.ensure((size_t)(s->dev.nTri ? s->dev.nTri : 1) * sizeof(TriPlanes)))) return rc;
 	if ((rc = c->recs.ensure((size_t)recCap * sizeof(SubTri)))) return rc;
 	if ((rc = c->recTiles.ensure((size_t)recCap * sizeof(uint2)))) return rc;
 	if ((rc = c->recLocal.ensure((size_t)recCap * 8 * 4))) return rc;
 	if ((rc = c->bigQueue.ensure((size_t)recCap * 4))) return rc;
 	if ((rc = c->clipQueue.ensure((size_t)(g.count ? g.count : 1) * 4))) return rc;
-	if ((rc = c->counters.ensure(64))) return rc;
-	if ((rc = c->tileCount.ensure((size_t)nTiles * 4))) return rc;
-	if ((rc = c->tileCountBig.ensure((size_t)nTiles * 4))) return rc;
-	if ((rc = c->tileCountA.ensure((size_t)nTiles * 4))) return rc;
+	if (nTiles > c->zeroCapTiles || !c->zeroSets.p) {
+		// both sets start out zero; from here on every pass's k_setup zeroes the set of the pass after it
+		const uint32_t cap = nTiles + nTiles / 4 + 64;
+		c->zeroCapTiles = 0;
+		if ((rc = c->zeroSets.ensure(2 * (16 + 3 * (size_t)cap) * 4))) return rc;
+		c->zeroCapTiles = cap; c->zset = 0;
+		HIP_CHECK(hipMemsetAsync(c->zeroSets.p, 0, 2 * (16 + 3 * (size_t)cap) * 4, c->stream));
+	} else {
+		c->zset ^= 1;
+	}
 	if ((rc = c->tileOffset.ensure((size_t)(nTiles + 1) * 4))) return rc;
 	if ((rc = c->cursor.ensure((size_t)nTiles * 4))) return rc;
 	if ((rc = c->tileFlags.ensure((size_t)nTiles * 8))) return rc; // per-tile flags, then the list of deep tiles
 	if ((rc = c->binList.ensure((size_t)binCap * 4))) return rc;
 	if (g.keys && (rc = c->binKeys.ensure((size_t)binCap * 4))) return rc;
 	c->recCap = recCap; c->binCap = binCap;
-	uint32_t* counters = c->counters.as<uint32_t>(); // [0] recCount, [1] overflow, [2] alpha tile count, [3] clip queue length, [4] big-record queue length, [5] deep alpha tile count
-	ZeroArgs z;
-	z.counters = counters; z.tiles0 = c->tileCount.as<uint32_t>(); z.tiles1 = c->tileCountA.as<uint32_t>();
-	z.tiles2 = c->tileCountBig.as<uint32_t>(); z.nTiles = nTiles;
-	{
-		StageTimer t(c, ST_XFORM);
-		vkr_launch_xform(c->stream, s->dev.pos, c->clip.as<float4>(), s->dev.nVert, g.M, z);
-	}
+	uint32_t* counters = c->counters();
 	{
 		StageTimer t(c, ST_SETUP);
 		SetupArgs a;
-		a.sc = s->dev; a.view = g.view; a.clip = c->clip.as<float4>();
+		a.sc = s->dev; a.view = g.view; a.M = g.M;
+		a.zeroBase = c->zs(c->zset ^ 1); a.zeroWords = 16 + 3 * c->zeroCapTiles;
 		a.first = g.first; a.count = g.count; a.cullOpaque = g.cullOpaque; a.cullAlpha = g.cullAlpha;
 		a.useOrderB = g.useOrderB; a.alphaTest = g.alphaTest; a.shadow = g.shadow;
 		a.guard = vkr_guard_band(g.view.W, g.view.H);
 		a.recs = c->recs.as<SubTri>(); a.recTiles = c->recTiles.as<uint2>(); a.recCap = recCap;
-		a.recCount = counters; a.tileCount = c->tileCount.as<uint32_t>(); a.overflow = counters + 1;
-		a.tileCountBig = c->tileCountBig.as<uint32_t>(); a.tileCountA = c->tileCountA.as<uint32_t>(); a.recLocal = c->recLocal.as<uint32_t>();
+		a.recCount = counters; a.tileCount = c->tileCount(); a.overflow = counters + 1;
+		a.tileCountBig = c->tileCountBig(); a.tileCountA = c->tileCountA(); a.recLocal = c->recLocal.as<uint32_t>();
 		a.clipQueue = c->clipQueue.as<uint32_t>(); a.clipCount = counters + 3; a.bigQueue = c->bigQueue.as<uint32_t>(); a.bigCount = counters + 4; a.planes = c->planes.as<TriPlanes>();
 		vkr_launch_setup(c->stream, a);
 	}
 	{
 		StageTimer t(c, ST_BIN_SCAN);
-		vkr_launch_scan_tiles(c->stream, c->tileCount.as<uint32_t>(), c->tileCountA.as<uint32_t>(), c->tileCountBig.as<uint32_t>(), c->tileOffset.as<uint32_t>(), c->cursor.as<uint32_t>(), nTiles,
+		vkr_launch_scan_tiles(c->stream, c->tileCount(), c->tileCountA(), c->tileCountBig(), c->tileOffset.as<uint32_t>(), c->cursor.as<uint32_t>(), nTiles,
 		                      binCap, counters + 1, &c->hStatus[statusSlot].recCount);
 	}
 	{
 		StageTimer t(c, ST_BIN_FILL);
 		BinFillArgs b;
 		b.recs = c->recs.as<SubTri>(); b.recTiles = c->recTiles.as<uint2>(); b.recCount = counters; b.baseCount = g.count; b.recCap = recCap;
-		b.tileOffset = c->tileOffset.as<uint32_t>(); b.tileCount = c->tileCount.as<uint32_t>(); b.tileCountA = c->tileCountA.as<uint32_t>(); b.recLocal = c->recLocal.as<uint32_t>(); b.bigQueue = c->bigQueue.as<uint32_t>(); b.bigCount = counters + 4; b.cursor = c->cursor.as<uint32_t>(); b.binList = c->binList.as<uint32_t>();
+		b.tileOffset = c->tileOffset.as<uint32_t>(); b.tileCount = c->tileCount(); b.tileCountA = c->tileCountA(); b.recLocal = c->recLocal.as<uint32_t>(); b.bigQueue = c->bigQueue.as<uint32_t>(); b.bigCount = counters + 4; b.cursor = c->cursor.as<uint32_t>(); b.binList = c->binList.as<uint32_t>();
 		b.keys = g.keys ? c->binKeys.as<uint32_t>() : nullptr; b.binCap = binCap; b.tilesX = g.view.tilesX;
 		vkr_launch_bin_fill(c->stream, b, recCap);
 	}
@@ -952,10 +960,10 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 static void fill_raster_args(vkr_context* c, const vkr_scene* s, const ViewDev& view, RasterArgs& r)
 {
 	r.sc = s->dev; r.view = view; r.clip = c->clip.as<float4>(); r.planes = c->planes.as<TriPlanes>(); r.recs = c->recs.as<SubTri>();
-	r.tileOffset = c->tileOffset.as<uint32_t>(); r.tileCount = c->tileCount.as<uint32_t>(); r.tileCountA = c->tileCountA.as<uint32_t>(); r.binList = c->binList.as<uint32_t>(); r.binCap = c->binCap;
+	r.tileOffset = c->tileOffset.as<uint32_t>(); r.tileCount = c->tileCount(); r.tileCountA = c->tileCountA(); r.binList = c->binList.as<uint32_t>(); r.binCap = c->binCap;
 	r.vis = nullptr; r.depthOut = nullptr; r.countOut = nullptr;
 	r.alphaTiles = c->tileFlags.as<uint32_t>(); r.alphaPass = 0;
-	r.deepTiles = c->tileFlags.as<uint32_t>() + (size_t)view.tilesX * view.tilesY; r.deepTileCount = c->counters.as<uint32_t>() + 5; r.alphaTileCount = c->counters.as<uint32_t>() + 2;
+	r.deepTiles = c->tileFlags.as<uint32_t>() + (size_t)view.tilesX * view.tilesY; r.deepTileCount = c->counters() + 5; r.alphaTileCount = c->counters() + 2;
 }
 
 static int copy_out(vkr_context* c, void* dst, const void* src, size_t bytes)

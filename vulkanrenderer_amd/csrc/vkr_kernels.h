@@ -2,17 +2,12 @@
 #pragma once
 #include "vkr_device.h"
 
-// counters k_xform zeroes for the kernels after it: 16 scalar counters and three per-tile arrays
-struct ZeroArgs {
-	uint32_t* counters;
-	uint32_t* tiles0; uint32_t* tiles1; uint32_t* tiles2;
-	uint32_t nTiles;
-};
-
 struct SetupArgs {
 	SceneDev sc;
 	ViewDev view;
-	const float4* clip;
+	Mat4 M;                    // object -> clip space of the pass (projCam, or the light's depthMVP)
+	uint32_t* zeroBase;        // the counter set of the NEXT pass: k_setup zeroes it while this pass uses the other one
+	uint32_t zeroWords;
 	uint32_t first, count;     // triangle range, submission order A
 	int cullOpaque, cullAlpha; // 0 none, 1 back; alpha-masked meshes start at sc.nTriOpaque
 	int useOrderB;             // prim = file-order rank (passes that draw every mesh in file order)
@@ -115,7 +110,6 @@ struct LightArgs {
 	uint32_t clearColour; // packed RGBA8 of the render pass clear value
 };
 
-void vkr_launch_xform(hipStream_t s, const float* pos, float4* clip, uint32_t nVert, const Mat4& M, const ZeroArgs& z);
 void vkr_launch_setup(hipStream_t s, const SetupArgs& a);
 void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countA, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
                            uint32_t nTiles, uint32_t cap, uint32_t* overflow, uint32_t* statusOut);
