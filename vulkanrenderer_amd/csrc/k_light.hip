@@ -34,19 +34,23 @@ template <bool SAMECOL>
 __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 {
 	__shared__ float sT[257];
-	vkr_load_srgb_table(sT, a.srgbThresh);
-	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
 	// a workgroup shades 32x8 pixels, each wavefront an 8x8 block: the pixels of a wavefront mostly lie on
 	// one surface, which is what lets whole wavefronts skip the lights behind it (below), and a workgroup's
 	// rows are whole 128-byte lines of the depth buffer (16 pixels wide, half of each line was fetched twice)
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	const uint32_t x = blockIdx.x * 32u + wv * 8u + (lane & 7u), y = blockIdx.y * 8u + (lane >> 3);
-	if (x >= rw || y >= rh) return;
+	const bool inside = x < rw && y < rh;
 	const uint32_t p = y * rw + x;
-	const float depth = a.depth[p];
+	// the pixel's inputs are requested before the encode table's round trip and the barrier behind it
+	float depth = 1.0f;
+	uint2 gn = make_uint2(0u, 0u), ga = gn;
+	if (inside) { depth = a.depth[p]; gn = a.gN[p]; ga = a.gA[p]; }
+	vkr_load_srgb_table(sT, a.srgbThresh);
+	__syncthreads();
+	if (!inside) return;
 	if (depth == 1.0f) { a.colour[p] = a.clearColour; return; } // discard: the clear colour stays
-	a.colour[p] = vkr_light_pixel<SAMECOL>(a, sT, depth, a.gN[p], a.gA[p], x, y);
+	a.colour[p] = vkr_light_pixel<SAMECOL>(a, sT, depth, gn, ga, x, y);
 }
 
 // overVisRead.frag:7-13: oColor = (0,0.3,0,0.1) + vec4(vec3(stencil/25), 0).  The colour depends on the
