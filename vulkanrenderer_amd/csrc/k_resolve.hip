@@ -105,15 +105,18 @@ __device__ __forceinline__ void decode_key(unsigned long long key, float& depth,
 __global__ __launch_bounds__(256) void k_resolve_gbuf(ResolveArgs a)
 {
 	__shared__ float sDec[256];
-	sDec[threadIdx.x] = a.sc.srgbDecode[threadIdx.x];
-	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
 	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-	if (x >= rw || y >= rh) return;
+	const bool inside = x < rw && y < rh;
 	const size_t p = (size_t)y * rw + x;
+	// the visibility key is requested before the decode table's round trip and the barrier behind it
+	const unsigned long long key = inside ? a.vis[p] : 0ull;
+	sDec[threadIdx.x] = a.sc.srgbDecode[threadIdx.x];
+	__syncthreads();
+	if (!inside) return;
 	const int px = (int)(a.view.x0 + x), py = (int)(a.view.y0 + y);
 	float depth; uint32_t prim;
-	decode_key(a.vis[p], depth, prim);
+	decode_key(key, depth, prim);
 	a.depth[p] = depth;
 	if (a.triId) a.triId[p] = prim;
 	// attachment clears 0.1 (main/main.cpp:3843-3851): half(0.1) = 0x2E66
@@ -188,16 +191,18 @@ __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 {
 	__shared__ float sDec[256];
 	__shared__ float sT[257];
+	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
+	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+	const bool inside = x < rw && y < rh;
+	const size_t p = (size_t)y * rw + x;
+	const unsigned long long key = inside ? a.vis[p] : 0ull; // requested before the tables' round trip
 	sDec[threadIdx.x] = a.sc.srgbDecode[threadIdx.x];
 	vkr_load_srgb_table(sT, a.sc.srgbThresh);
 	__syncthreads();
-	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
-	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-	if (x >= rw || y >= rh) return;
-	const size_t p = (size_t)y * rw + x;
+	if (!inside) return;
 	const int px = (int)(a.view.x0 + x), py = (int)(a.view.y0 + y);
 	float depth; uint32_t prim;
-	decode_key(a.vis[p], depth, prim);
+	decode_key(key, depth, prim);
 	if (a.depth) a.depth[p] = depth;
 	if (a.triId) a.triId[p] = prim;
 	// clear colour (0.1,0.1,0.1,1), main/main.cpp:3988-3991
@@ -315,17 +320,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 {
 	__shared__ float sDec[256];
 	__shared__ float sT[257];
-	sDec[threadIdx.x] = a.sc.srgbDecode[threadIdx.x];
-	vkr_load_srgb_table(sT, l.srgbThresh);
-	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	const uint32_t x = blockIdx.x * 16u + (wv & 1u) * 8u + (lane & 7u), y = blockIdx.y * 16u + (wv >> 1) * 8u + (lane >> 3);
-	if (x >= rw || y >= rh) return;
+	const bool inside = x < rw && y < rh;
 	const size_t p = (size_t)y * rw + x;
+	const unsigned long long key = inside ? a.vis[p] : 0ull; // requested before the tables' round trip
+	sDec[threadIdx.x] = a.sc.srgbDecode[threadIdx.x];
+	vkr_load_srgb_table(sT, l.srgbThresh);
+	__syncthreads();
+	if (!inside) return;
 	const int px = (int)(a.view.x0 + x), py = (int)(a.view.y0 + y);
 	float depth; uint32_t prim;
-	decode_key(a.vis[p], depth, prim);
+	decode_key(key, depth, prim);
 	if (a.depth) a.depth[p] = depth;
 	if (a.triId) a.triId[p] = prim;
 	uint2 gn = make_uint2(0x2E662E66u, 0x2E662E66u), ga = gn; // attachment clears 0.1
