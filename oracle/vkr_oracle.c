@@ -1426,6 +1426,16 @@ ORA_API int ora_render_rows(const ora_scene* sc, const vkr_frame_params* fp, con
 		f.pipe = PIPE_GBUF;
 		draw_range(&f, sc->orderA, 0, sc->nPrim, u->sceneUniforms.projCam, 1, 0, f.W, f.H);
 		deferred_light_pass(&f);
+		if ((fp->flags & VKR_FRAME_SHADOW_PASS) && out->shadow_map) {
+			/* the "deferred + shadow map" composition (not a reference combination: its deferred path records no
+			 * shadow pass, main/main.cpp:3836-3946): the light's depth pass of main/main.cpp:3950-3984 is drawn as
+			 * well and handed out; the lighting does not sample it */
+			needShadow = 1;
+			f.shadow = (float*)malloc((size_t)f.S * f.S * 4);
+			for (size_t i = 0; i < (size_t)f.S * f.S; i++) f.shadow[i] = 1.0f;
+			f.pipe = PIPE_SHADOW;
+			draw_range(&f, sc->orderA, 0, sc->nPrimOpaque, u->depthMVPUniform.depthMVP, 0, 0, f.S, f.S);
+		}
 	} else if (!fp->mosaicEffect && dbg == 1) {
 		needShadow = 1;
 		f.shadow = (float*)malloc((size_t)f.S * f.S * 4);
