@@ -455,7 +455,10 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 			double Az = 0.0, Bz = 0.0, Cz = 0.0;
 			if (valid) { j = sOrder[tid]; bb = sCov[j].bbox; Az = sCov[j].Az; Bz = sCov[j].Bz; Cz = sCov[j].Cz; }
 			const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
-			const float slack = (float)(3.5 * (fabs(Az) + fabs(Bz))) + 2.0e-6f;
+			// the bound must never exceed the nearest depth a fragment of the block can take: plane at the block's centre
+			// minus the largest change over 3.5 pixels either way, in double, then rounded towards minus infinity (a
+			// fragment's own depth is the plane's double value rounded to nearest, which rounding down never exceeds)
+			const double slack = 3.5 * (fabs(Az) + fabs(Bz));
 			uint32_t pos[4];
 			bool ov[4];
 			float zn[4];
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 				const int bx = qx + (b & 1) * 8, by = qy + (b >> 1) * 8;
 				ov[b] = valid && !(x1 < bx || x0 > bx + 7 || y1 < by || y0 > by + 7);
 				// nearest depth the plane can take over the block's pixel centres
-				zn[b] = (float)fma(Az, (double)(ox + bx) + 4.0, fma(Bz, (double)(oy + by) + 4.0, Cz)) - slack;
+				zn[b] = __double2float_rd(fma(Az, (double)(ox + bx) + 4.0, fma(Bz, (double)(oy + by) + 4.0, Cz)) - slack);
 				const unsigned long long mask = __ballot(ov[b]);
 				pos[b] = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 				if (tid < 128 && lane == 0) { if (wid == 0) sCnt0[b] = (uint32_t)__popcll(mask); else sListN[b] = (uint32_t)__popcll(mask); }
@@ -579,12 +582,81 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 // order (main/main.cpp:2781-2797, 4122-4123).  Order matters, so the kernel is
 // pixel-owner like k_raster_alpha: one 1024-thread workgroup per tile, a
 // wavefront per 8x8 block, a lane per pixel holding its depth and counter in
-// registers, walking the tile's bin - sorted by primitive - staged through LDS
-// 256 entries at a time with the edge functions set up once per entry.
+// registers.  The workgroup first sorts the tile's bin by primitive - a bitonic
+// network over (primitive << 32 | record) words in LDS; bins longer than the
+// LDS array are sorted in place in their global segment, the long-distance
+// steps in global memory and the short ones chunk by chunk through LDS - and
+// then walks it, staged through LDS 256 entries at a time with the edge
+// functions set up once per entry.
 // ---------------------------------------------------------------------------
+#define OS_SORT_CAP 4096u // bin entries sorted entirely in LDS (32 KB)
+
+// Compare-exchange steps of the normalised bitonic network (every comparator puts the smaller word at the lower
+// index, so positions >= n behave as +infinity padding that never moves).  One step pairs i with i ^ mask.
+__device__ __forceinline__ void os_lds_step(unsigned long long* s, uint32_t m, uint32_t mask, uint32_t tid)
+{
+	for (uint32_t i = tid; i < m; i += 1024u) {
+		const uint32_t l = i ^ mask;
+		if (l > i && l < m) {
+			const unsigned long long x = s[i], y = s[l];
+			if (y < x) { s[i] = y; s[l] = x; }
+		}
+	}
+	__syncthreads();
+}
+
+// sorts s[0, m) (m a power of two <= OS_SORT_CAP) ascending; steps with block size <= kFrom / 2 are taken as done
+__device__ __forceinline__ void os_lds_sort(unsigned long long* s, uint32_t m, uint32_t tid)
+{
+	for (uint32_t k = 2u; k <= m; k <<= 1) {
+		os_lds_step(s, m, k - 1u, tid);
+		for (uint32_t j = k >> 2; j >= 1u; j >>= 1) os_lds_step(s, m, j, tid);
+	}
+}
+
+__device__ __forceinline__ void os_global_step(uint32_t* keys, uint32_t* vals, uint32_t n, uint32_t m, uint32_t mask, uint32_t tid)
+{
+	for (uint32_t i = tid; i < m; i += 1024u) {
+		const uint32_t l = i ^ mask;
+		if (l > i && l < n) {
+			const unsigned long long x = ((unsigned long long)keys[i] << 32) | vals[i], y = ((unsigned long long)keys[l] << 32) | vals[l];
+			if (y < x) { keys[i] = (uint32_t)(y >> 32); vals[i] = (uint32_t)y; keys[l] = (uint32_t)(x >> 32); vals[l] = (uint32_t)x; }
+		}
+	}
+	__syncthreads(); // one workgroup owns the segment: its own stores are visible to it behind the barrier
+}
+
+// In-place sort of a bin longer than the LDS array: (keys[i], vals[i]) ascending by (key, val).
+__device__ __noinline__ void os_sort_long(unsigned long long* s, uint32_t* keys, uint32_t* vals, uint32_t n, uint32_t tid)
+{
+	uint32_t m = OS_SORT_CAP;
+	while (m < n) m <<= 1;
+	const uint32_t chunks = (n + OS_SORT_CAP - 1u) / OS_SORT_CAP;
+	for (uint32_t k = OS_SORT_CAP; k <= m; k <<= 1) {
+		// block size k: the first round sorts every chunk outright; later rounds take the steps that pair positions
+		// at least OS_SORT_CAP apart in global memory, then finish every chunk's remaining steps in LDS
+		if (k > OS_SORT_CAP) {
+			os_global_step(keys, vals, n, m, k - 1u, tid);
+			for (uint32_t j = k >> 2; j >= OS_SORT_CAP; j >>= 1) os_global_step(keys, vals, n, m, j, tid);
+		}
+		for (uint32_t c = 0; c < chunks; c++) {
+			const uint32_t base = c * OS_SORT_CAP;
+			for (uint32_t i = tid; i < OS_SORT_CAP; i += 1024u)
+				s[i] = (base + i < n) ? (((unsigned long long)keys[base + i] << 32) | vals[base + i]) : ~0ull;
+			__syncthreads();
+			if (k == OS_SORT_CAP) os_lds_sort(s, OS_SORT_CAP, tid);
+			else for (uint32_t j = OS_SORT_CAP >> 1; j >= 1u; j >>= 1) os_lds_step(s, OS_SORT_CAP, j, tid);
+			for (uint32_t i = tid; i < OS_SORT_CAP; i += 1024u)
+				if (base + i < n) { keys[base + i] = (uint32_t)(s[i] >> 32); vals[base + i] = (uint32_t)s[i]; }
+			__syncthreads();
+		}
+	}
+}
+
 __global__ __launch_bounds__(1024) void k_overshade(OvershadeArgs a)
 {
 	__shared__ AlphaCover sCov[ALPHA_CHUNK];
+	__shared__ unsigned long long sSort[OS_SORT_CAP];
 	const uint32_t tile = blockIdx.x;
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
 	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = (int)(a.view.y0 + ty * VKR_TILE);
@@ -602,10 +674,23 @@ __global__ __launch_bounds__(1024) void k_overshade(OvershadeArgs a)
 	if (end > a.binCap) end = a.binCap;
 	if (beg > end) beg = end;
 	const uint32_t n = end - beg;
+	// submission order: the bin sorted by primitive (two fan triangles of one clipped primitive never cover the same
+	// pixel, so their mutual order is immaterial; the record index makes the order total all the same)
+	const bool inLds = n <= OS_SORT_CAP;
+	if (inLds) {
+		uint32_t m = 1u;
+		while (m < n) m <<= 1;
+		for (uint32_t i = tid; i < m; i += 1024u)
+			sSort[i] = (i < n) ? (((unsigned long long)a.binKeys[beg + i] << 32) | a.binList[beg + i]) : ~0ull;
+		__syncthreads();
+		os_lds_sort(sSort, m, tid);
+	} else {
+		os_sort_long(sSort, a.binKeys + beg, a.binList + beg, n, tid);
+	}
 	for (uint32_t base = 0; base < n; base += ALPHA_CHUNK) {
 		__syncthreads();
 		if (tid < ALPHA_CHUNK && base + tid < n) {
-			const SubTri s = a.recs[a.binList[beg + base + tid]];
+			const SubTri s = a.recs[inLds ? (uint32_t)sSort[base + tid] : a.binList[beg + base + tid]];
 			AlphaCover& c = sCov[tid];
 			int bx0, by0, bx1, by1;
 			tri_bbox(s, bx0, by0, bx1, by1);

@@ -62,12 +62,12 @@ template <class F> static int guarded(const char* fn, F&& body) noexcept
 // stages
 // ---------------------------------------------------------------------------
 enum Stage {
-	ST_SETUP, ST_BIN_SCAN, ST_BIN_FILL, ST_RASTER_VIS, ST_RASTER_SHADOW, ST_RASTER_COUNT, ST_SORT_BINS,
+	ST_SETUP, ST_BIN_SCAN, ST_BIN_FILL, ST_RASTER_VIS, ST_RASTER_SHADOW, ST_RASTER_COUNT,
 	ST_OVERSHADE, ST_RESOLVE_GBUF, ST_RESOLVE_FORWARD, ST_RESOLVE_DEBUG, ST_DEFERRED_LIGHT, ST_OVERVIS_COLOUR, ST_MOSAIC,
 	ST_COPY_OUT, ST_RESOLVE_LIGHT, ST_COUNT
 };
 static const char* kStageNames[ST_COUNT] = {
-	"k_setup", "k_scan_tiles", "k_bin_fill", "k_raster_vis", "k_raster_shadow", "k_raster_count", "sort_bins",
+	"k_setup", "k_scan_tiles", "k_bin_fill", "k_raster_vis", "k_raster_shadow", "k_raster_count",
 	"k_overshade", "k_resolve_gbuf", "k_resolve_forward", "k_resolve_debug", "k_deferred_light", "k_overvis_colour",
 	"k_mosaic", "copy_out", "k_resolve_light"
 };
@@ -108,7 +108,7 @@ struct vkr_context {
 	float* dThresh = nullptr; // 255
 	float hDecode[256], hThresh[255];
 	// geometry scratch
-	DevBuf clip, planes, recs, recTiles, recLocal, clipQueue, bigQueue, zeroSets, tileOffset, cursor, tileFlags, binList, binKeys, binList2, binKeys2, sortTemp;
+	DevBuf clip, planes, recs, recTiles, recLocal, clipQueue, bigQueue, zeroSets, tileOffset, cursor, tileFlags, binList, binKeys;
 	// counters + per-tile counts of a pass, twice: a pass uses one set while its k_setup zeroes the other for the next pass
 	// layout of a set: 16 counters ([0] recCount, [1] overflow, [2] alpha tile count, [3] clip queue length,
 	// [4] big-record queue length, [5] deep alpha tile count), then tileCount, tileCountA, tileCountBig (zeroCapTiles each)
@@ -478,7 +478,7 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	DevBuf* bufs[] = { &c->clip, &c->planes, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->bigQueue, &c->zeroSets, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
-		&c->binKeys, &c->binList2, &c->binKeys2, &c->sortTemp, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
+		&c->binKeys, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
 		&c->colour2, &c->stencil, &c->mip, &c->shadow };
 	for (DevBuf* b : bufs) b->release();
 	for (auto& t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -499,7 +499,7 @@ static hipEvent_t get_event(vkr_context* c)
 {
 	if (!c->eventPool.empty()) { hipEvent_t e = c->eventPool.back(); c->eventPool.pop_back(); return e; }
 	hipEvent_t e = nullptr;
-	(void)hipEventCreate(&e);
+	if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
 	return e;
 }
 
@@ -509,6 +509,13 @@ struct StageTimer {
 	{
 		if (!on) return;
 		t.stage = stage; t.a = get_event(c); t.b = get_event(c);
+		if (!t.a || !t.b) {
+			// no event to be had: this stage goes untimed rather than recording a null event
+			if (t.a) c->eventPool.push_back(t.a);
+			if (t.b) c->eventPool.push_back(t.b);
+			on = false;
+			return;
+		}
 		(void)hipEventRecord(t.a, c->stream);
 	}
 	~StageTimer()
@@ -611,6 +618,8 @@ static int scene_create_impl(vkr_context* c, const vkr_scene_desc* d, vkr_scene*
 	*out = nullptr;
 	HIP_CHECK(hipSetDevice(c->device));
 	// ---- validate
+	if ((d->textureCount && !d->textures) || (d->materialCount && !d->materials) || (d->meshCount && !d->meshes))
+		return set_error(VKR_E_INVALID, "vkr_scene_create: a count is non-zero but its array is NULL");
 	for (uint32_t i = 0; i < d->textureCount; i++) {
 		const vkr_texture_desc& t = d->textures[i];
 		if (!t.rgba8 || t.width == 0 || t.height == 0 || t.width > 32768 || t.height > 32768)
@@ -907,21 +916,23 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if ((rc = c->recLocal.ensure((size_t)recCap * 8 * 4))) return rc;
 	if ((rc = c->bigQueue.ensure((size_t)recCap * 4))) return rc;
 	if ((rc = c->clipQueue.ensure((size_t)(g.count ? g.count : 1) * 4))) return rc;
-	if (nTiles > c->zeroCapTiles || !c->zeroSets.p) {
-		// both sets start out zero; from here on every pass's k_setup zeroes the set of the pass after it
-		const uint32_t cap = nTiles + nTiles / 4 + 64;
-		c->zeroCapTiles = 0;
-		if ((rc = c->zeroSets.ensure(2 * (16 + 3 * (size_t)cap) * 4))) return rc;
-		c->zeroCapTiles = cap; c->zset = 0;
-		HIP_CHECK(hipMemsetAsync(c->zeroSets.p, 0, 2 * (16 + 3 * (size_t)cap) * 4, c->stream));
-	} else {
-		c->zset ^= 1;
-	}
 	if ((rc = c->tileOffset.ensure((size_t)(nTiles + 1) * 4))) return rc;
 	if ((rc = c->cursor.ensure((size_t)nTiles * 4))) return rc;
 	if ((rc = c->tileFlags.ensure((size_t)nTiles * 8))) return rc; // per-tile flags, then the list of deep tiles
 	if ((rc = c->binList.ensure((size_t)binCap * 4))) return rc;
 	if (g.keys && (rc = c->binKeys.ensure((size_t)binCap * 4))) return rc;
+	// every buffer of the pass is in place; only now is the counter-set state touched, so an allocation failure
+	// above leaves the ping-pong pair as the last complete pass left it
+	if (nTiles > c->zeroCapTiles || !c->zeroSets.p) {
+		// both sets start out zero; from here on every pass's k_setup zeroes the set of the pass after it
+		const uint32_t cap = nTiles + nTiles / 4 + 64;
+		c->zeroCapTiles = 0;
+		if ((rc = c->zeroSets.ensure(2 * (16 + 3 * (size_t)cap) * 4))) return rc;
+		HIP_CHECK(hipMemsetAsync(c->zeroSets.p, 0, 2 * (16 + 3 * (size_t)cap) * 4, c->stream));
+		c->zeroCapTiles = cap; c->zset = 0;
+	} else {
+		c->zset ^= 1;
+	}
 	c->recCap = recCap; c->binCap = binCap;
 	uint32_t* counters = c->counters();
 	{
@@ -1202,26 +1213,11 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 			// depth test disabled => no depth writes: the attachment keeps its clear value
 			vkr_launch_fill_u32(c->stream, c->depth.as<uint32_t>(), 0x3F800000u, n);
 		} else {
-			// submission order matters: sort every tile's bin by primitive.  The sort's
-			// segment offsets come from the device, so check them on the host first.
-			HIP_CHECK(hipStreamSynchronize(c->stream));
-			const PassStatus st = c->hStatus[statusSlot];
-			const uint32_t nTiles = view.tilesX * view.tilesY;
-			const uint32_t* vals = c->binList.as<uint32_t>();
-			if (!st.overflow && st.binTotal <= c->binCap && st.binTotal > 0) {
-				StageTimer t(c, ST_SORT_BINS);
-				if ((rc = c->binList2.ensure((size_t)c->binCap * 4)) || (rc = c->binKeys2.ensure((size_t)c->binCap * 4))) return rc;
-				const size_t tb = vkr_sort_bins_temp_bytes(st.binTotal, nTiles);
-				if ((rc = c->sortTemp.ensure(tb ? tb : 4))) return rc;
-				int which = vkr_sort_bins(c->stream, c->sortTemp.p, tb, c->binKeys.as<uint32_t>(), c->binKeys2.as<uint32_t>(),
-				                          c->binList.as<uint32_t>(), c->binList2.as<uint32_t>(), st.binTotal, nTiles,
-				                          c->tileOffset.as<uint32_t>());
-				if (which < 0) return set_error(VKR_E_DEVICE, "segmented sort of the tile bins failed");
-				vals = which ? c->binList2.as<uint32_t>() : c->binList.as<uint32_t>();
-			}
+			// submission order matters: the kernel sorts every tile's bin by primitive before walking it
 			StageTimer t(c, ST_OVERSHADE);
 			OvershadeArgs o;
-			o.view = view; o.recs = c->recs.as<SubTri>(); o.tileOffset = c->tileOffset.as<uint32_t>(); o.binList = vals;
+			o.view = view; o.recs = c->recs.as<SubTri>(); o.tileOffset = c->tileOffset.as<uint32_t>();
+			o.binList = c->binList.as<uint32_t>(); o.binKeys = c->binKeys.as<uint32_t>();
 			o.binCap = c->binCap; o.countOut = c->stencil.as<uint8_t>(); o.depthOut = c->depth.as<float>();
 			vkr_launch_overshade(c->stream, o);
 		}
@@ -1285,6 +1281,22 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 	return VKR_OK;
 }
 
+// A submit that failed half-way has kernels queued that still write this frame's status slots, may have forked work
+// onto the helper stream that nothing joins, and leaves the ping-pong counter sets in an unknown phase: drain both
+// streams and make the next pass start from freshly zeroed sets.
+static void recover_failed_submit(vkr_context* c)
+{
+	const std::string keep = g_err; // the caller reports the submit's error, not the clean-up's
+	(void)hipStreamSynchronize(c->stream);
+	if (c->shadowHelper) {
+		(void)hipStreamSynchronize(c->shadowHelper->stream);
+		c->shadowHelper->zeroCapTiles = 0;
+	}
+	c->zeroCapTiles = 0; // run_geometry re-zeroes both sets
+	(void)hipGetLastError();
+	snprintf(g_err, sizeof g_err, "%s", keep.c_str());
+}
+
 static int render_impl(vkr_context* c, const vkr_scene* s, const vkr_frame_params* fp, const vkr_frame_out* out)
 {
 	if (!c || !s || !fp || !out) return set_error(VKR_E_INVALID, "vkr_render: NULL argument");
@@ -1301,7 +1313,7 @@ static int render_impl(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 	PendingFrame pf;
 	pf.scene = s; pf.params = *fp; pf.out = *out; pf.statusSlot = c->statusUsed; pf.nPasses = 0;
 	memset(&c->hStatus[pf.statusSlot], 0, sizeof(PassStatus) * 2);
-	if ((rc = submit_frame(c, s, pf.params, pf.out, pf.statusSlot, &pf.nPasses))) return rc;
+	if ((rc = submit_frame(c, s, pf.params, pf.out, pf.statusSlot, &pf.nPasses))) { recover_failed_submit(c); return rc; }
 	c->statusUsed += 2;
 	c->pending.push_back(pf);
 	return VKR_OK;
@@ -1312,6 +1324,10 @@ static int wait_impl(vkr_context* c)
 	if (!c) return set_error(VKR_E_INVALID, "vkr_wait: NULL context");
 	HIP_CHECK(hipSetDevice(c->device));
 	HIP_CHECK(hipStreamSynchronize(c->stream));
+	// stage timers are folded into the totals at every fence, so their events return to the pool however long the
+	// host goes without reading the profile
+	drain_timers(c);
+	if (c->shadowHelper) { HIP_CHECK(hipStreamSynchronize(c->shadowHelper->stream)); drain_timers(c->shadowHelper); }
 	// a pass that ran out of record or bin space produced an incomplete image:
 	// grow the scratch buffers and render those frames again
 	for (int attempt = 0; attempt < 6; attempt++) {
@@ -1335,7 +1351,7 @@ static int wait_impl(vkr_context* c)
 			memset(&c->hStatus[c->statusUsed], 0, sizeof(PassStatus) * 2);
 			pf.statusSlot = c->statusUsed;
 			int rc = submit_frame(c, pf.scene, pf.params, pf.out, pf.statusSlot, &pf.nPasses);
-			if (rc) return rc;
+			if (rc) { recover_failed_submit(c); c->pending.clear(); c->statusUsed = 0; return rc; }
 			c->statusUsed += 2;
 			c->pending.push_back(pf);
 		}

@@ -76,7 +76,8 @@ struct OvershadeArgs {
 	ViewDev view;
 	const SubTri* recs;
 	const uint32_t* tileOffset;
-	const uint32_t* binList; // sorted by prim inside each tile
+	uint32_t* binList;       // the tiles' bins and, per entry, its primitive: the kernel orders a tile's entries by
+	uint32_t* binKeys;       // primitive itself (bins too long for its LDS array are sorted in place)
 	uint32_t binCap;
 	uint8_t* countOut;
 	float* depthOut;
@@ -132,7 +133,3 @@ void vkr_launch_tri_shade(hipStream_t s, const SceneDev& sc, TriShade* out);
 void vkr_launch_pack_chain(hipStream_t s, const uint32_t* rgb, const uint32_t* a, uint32_t* out, uint32_t n);
 void vkr_launch_tbn_table(hipStream_t s, const uint32_t* tcomp, float4* out, uint32_t nVert);
 void vkr_launch_fill_u32(hipStream_t s, uint32_t* dst, uint32_t value, size_t n);
-// segmented sort of bin entries by prim (ordered passes); temp storage managed by the caller
-size_t vkr_sort_bins_temp_bytes(uint32_t maxEntries, uint32_t nTiles);
-int vkr_sort_bins(hipStream_t s, void* temp, size_t tempBytes, uint32_t* keysIn, uint32_t* keysOut, uint32_t* valsIn,
-                  uint32_t* valsOut, uint32_t maxEntries, uint32_t nTiles, const uint32_t* tileOffset);

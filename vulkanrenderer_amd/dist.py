@@ -62,7 +62,11 @@ class BandCompositor:
             dist.all_gather(self.gathered, src)
         else:
             dist.gather(src, self.gathered, dst=0)
-            if self.rank != 0:
-                return None
+        if not self.host:
+            # the collective is only enqueued (on torch's RCCL stream); `local` is also the renderer's output buffer,
+            # written by the next frame on the renderer's own stream, so the send must have finished before this returns
+            torch.cuda.current_stream().synchronize()
+        if not self.everywhere and self.rank != 0:
+            return None
         rows = [g[: r[3] - r[1]] for g, r in zip(self.gathered, self.rects) if r[3] > r[1]]
         return torch.cat(rows, dim=0)
