@@ -62,7 +62,7 @@ class BandCompositor:
             dist.all_gather(self.gathered, src)
         else:
             dist.gather(src, self.gathered, dst=0)
-        if not self.host:
+        if self.local.is_cuda and not self.host:
             # the collective is only enqueued (on torch's RCCL stream); `local` is also the renderer's output buffer,
             # written by the next frame on the renderer's own stream, so the send must have finished before this returns
             torch.cuda.current_stream().synchronize()
