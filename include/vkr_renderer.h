@@ -223,6 +223,27 @@ VKR_API int vkr_scene_read_texture_level(const vkr_scene* scene, uint32_t tex, u
  * Output pointers must stay valid until vkr_wait(). */
 VKR_API int vkr_render(vkr_context* ctx, const vkr_scene* scene, const vkr_frame_params* params,
                const vkr_frame_out* out);
+/* vkr_render for callers that cannot allocate.  It has no counterpart in the reference; it is for hosts that may
+ * not call hipMalloc while they render: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation.  Same parameters, same kernels and the same output as vkr_render, but every device buffer of the frame
+ * (triangle records, tile bins, visibility buffer, G-buffer, shadow map, ...) is a slice of one fixed array of
+ * VKR_STATIC_SCRATCH_BYTES that the library's device image holds on each GPU it runs on until the process ends, and
+ * nothing is created, grown or freed: no hipMalloc / hipFree / hipHostMalloc, no events, no helper stream (a forward
+ * frame's light pass runs on the frame's own stream), no stage timing.
+ *  - A frame that does not fit (about 200 bytes per triangle of the scene + 36 bytes per pixel + 4 bytes per
+ *    shadow-map texel; the SunTemple-proxy scene fits up to 1920x1080) is rejected with VKR_E_LIMIT; a pass whose
+ *    tile bins outgrow their slice is reported with VKR_E_LIMIT by vkr_wait and the frame is incomplete (vkr_render
+ *    would have grown the bins and rendered it again).
+ *  - At most VKR_STATIC_MAX_PENDING such frames between two vkr_wait calls.
+ *  - Frames run on the context's stream in submission order, among its vkr_render frames.  All contexts of a GPU
+ *    share that GPU's array: allocation-free frames of two contexts (or two processes' worth of threads) that overlap
+ *    on one GPU race; give each GPU one context that uses this entry point.
+ *  - Output pointers in device memory (or pinned host memory) keep the whole call free of staging allocations
+ *    inside the HIP runtime. */
+#define VKR_STATIC_SCRATCH_BYTES (256u << 20)
+#define VKR_STATIC_MAX_PENDING 64
+VKR_API int vkr_render_static(vkr_context* ctx, const vkr_scene* scene, const vkr_frame_params* params,
+                      const vkr_frame_out* out);
 /* The fence: blocks until every frame submitted on the context is complete
  * (vkWaitForFences, main/main.cpp:1268). */
 VKR_API int vkr_wait(vkr_context* ctx);

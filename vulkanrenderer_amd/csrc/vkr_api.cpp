@@ -72,12 +72,32 @@ static const char* kStageNames[ST_COUNT] = {
 	"k_mosaic", "copy_out", "k_resolve_light"
 };
 
+// The allocation-free entry point (vkr_render_static) draws every device buffer of a frame from one fixed array that
+// lives in the library's device image: file scope, a stated maximum size, one copy per GPU, held until the process
+// ends.  In host code the array's name only stands in for the symbol; its device address is looked up once per device
+// (static_scratch_base) and everything - kernel arguments, memsets, copies - works on that address.
+static __device__ __align__(256) unsigned char scratch[VKR_STATIC_SCRATCH_BYTES];
+
+struct Arena {
+	char* base = nullptr;
+	size_t size = 0, used = 0;
+};
+
 struct DevBuf {
 	void* p = nullptr;
 	size_t cap = 0;
+	Arena* arena = nullptr; // set: the buffer is a slice of the static scratch array, handed out anew for every frame
 	int ensure(size_t bytes)
 	{
-		if (bytes <= cap) return VKR_OK;
+		if (p && bytes <= cap) return VKR_OK;
+		if (arena) {
+			const size_t at = (arena->used + 255u) & ~(size_t)255u;
+			if (at + bytes > arena->size)
+				return set_error(VKR_E_LIMIT, "vkr_render_static: the frame needs more than the %zu bytes of static scratch (%zu in use, %zu more asked for); "
+				                              "render it with vkr_render", arena->size, arena->used, bytes);
+			p = arena->base + at; cap = bytes; arena->used = at + bytes;
+			return VKR_OK;
+		}
 		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
 		size_t want = bytes + bytes / 8 + 256;
 		hipError_t e = hipMalloc(&p, want);
@@ -85,7 +105,7 @@ struct DevBuf {
 		cap = want;
 		return VKR_OK;
 	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	void release() { if (p && !arena) (void)hipFree(p); p = nullptr; cap = 0; }
 	template <class T> T* as() const { return (T*)p; }
 };
 
@@ -142,7 +162,22 @@ struct vkr_context {
 	// own) beside the camera's geometry and raster passes; the two streams fork and join through these events
 	vkr_context* shadowHelper = nullptr;
 	hipEvent_t evFork = nullptr, evJoin = nullptr;
+	// allocation-free frames (vkr_render_static): a context of its own kind that borrows this one's stream and tables,
+	// takes every device buffer from the static scratch array and never grows anything
+	vkr_context* staticCtx = nullptr;
+	bool isStatic = false;
+	Arena arena;
 };
+
+// every device buffer a context owns
+#define VKR_CTX_NBUFS 23
+static void ctx_bufs(vkr_context* c, DevBuf* out[VKR_CTX_NBUFS])
+{
+	DevBuf* all[VKR_CTX_NBUFS] = { &c->clip, &c->planes, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->bigQueue, &c->zeroSets,
+		&c->tileOffset, &c->cursor, &c->tileFlags, &c->binList, &c->binKeys, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
+		&c->colour2, &c->stencil, &c->mip, &c->shadow };
+	for (int i = 0; i < VKR_CTX_NBUFS; i++) out[i] = all[i];
+}
 
 struct HostTex { uint32_t w[VKR_MAX_LEVELS], h[VKR_MAX_LEVELS], off[VKR_MAX_LEVELS]; int levels; int srgb; };
 
@@ -440,9 +475,27 @@ extern "C" void vkr_update_user_state(vkr_user_state* st, float elapsed)
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
-extern "C" int vkr_context_create(int device, vkr_context** out)
+// Device address of the static scratch array on `device` (which must be current), looked up once per device.
+#define VKR_MAX_DEVICES 64
+static void* g_scratchBase[VKR_MAX_DEVICES];
+static int static_scratch_base(int device, void** base)
 {
-	if (!out) return set_error(VKR_E_INVALID, "vkr_context_create: out is NULL");
+	if (device < 0 || device >= VKR_MAX_DEVICES) return set_error(VKR_E_LIMIT, "device %d: the static scratch table holds %d devices", device, VKR_MAX_DEVICES);
+	if (!g_scratchBase[device]) {
+		void* ptr = nullptr;
+		hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+		if (e != hipSuccess || !ptr) return set_error(VKR_E_DEVICE, "hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(e));
+		g_scratchBase[device] = ptr;
+	}
+	*base = g_scratchBase[device];
+	return VKR_OK;
+}
+
+// kind: 0 = a context of the caller's (vkr_context_create), 1 = a lane or helper of `owner` (stream, scratch and tables
+// of its own), 2 = the allocation-free context of `owner` (borrows its stream and tables, device buffers from the
+// static scratch array)
+static int context_create_impl(int device, vkr_context** out, int kind, vkr_context* owner)
+{
 	*out = nullptr;
 	int count = 0;
 	HIP_CHECK(hipGetDeviceCount(&count));
@@ -451,20 +504,49 @@ extern "C" int vkr_context_create(int device, vkr_context** out)
 	vkr_context* c = new (std::nothrow) vkr_context();
 	if (!c) return set_error(VKR_E_NOMEM, "out of host memory");
 	c->device = device;
+	c->parent = owner;
 	for (int i = 0; i < 256; i++) c->hDecode[i] = (float)srgb_eotf((double)i / 255.0);
 	for (int i = 0; i < 255; i++) c->hThresh[i] = (float)srgb_eotf(((double)i + 0.5) / 255.0);
-	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipMalloc((void**)&c->dDecode, 256 * sizeof(float));
-	if (e == hipSuccess) e = hipMalloc((void**)&c->dThresh, 256 * sizeof(float));
-	if (e == hipSuccess) e = hipMemcpy(c->dDecode, c->hDecode, 256 * sizeof(float), hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMemcpy(c->dThresh, c->hThresh, 255 * sizeof(float), hipMemcpyHostToDevice);
-	if (e != hipSuccess) {
-		int rc = set_error(VKR_E_DEVICE, "vkr_context_create: %s", hipGetErrorString(e));
+	int rc = VKR_OK;
+	hipError_t e = hipSuccess;
+	if (kind == 2) {
+		c->isStatic = true;
+		c->stream = owner->stream; c->dDecode = owner->dDecode; c->dThresh = owner->dThresh;
+		void* base = nullptr;
+		rc = static_scratch_base(device, &base);
+		if (!rc) {
+			c->arena.base = (char*)base; c->arena.size = VKR_STATIC_SCRATCH_BYTES; c->arena.used = 0;
+			DevBuf* b[VKR_CTX_NBUFS];
+			ctx_bufs(c, b);
+			for (DevBuf* d : b) d->arena = &c->arena;
+			// everything a frame needs on the host side exists before the first frame: status slots, the pending list
+			c->pending.reserve(VKR_STATIC_MAX_PENDING);
+			e = hipHostMalloc((void**)&c->hStatus, sizeof(PassStatus) * 2 * VKR_STATIC_MAX_PENDING, hipHostMallocDefault);
+			if (e == hipSuccess) c->statusCap = 2 * VKR_STATIC_MAX_PENDING;
+		}
+	} else {
+		e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipMalloc((void**)&c->dDecode, 256 * sizeof(float));
+		if (e == hipSuccess) e = hipMalloc((void**)&c->dThresh, 256 * sizeof(float));
+		if (e == hipSuccess) e = hipMemcpy(c->dDecode, c->hDecode, 256 * sizeof(float), hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(c->dThresh, c->hThresh, 255 * sizeof(float), hipMemcpyHostToDevice);
+	}
+	if (e != hipSuccess) rc = set_error(VKR_E_DEVICE, "vkr_context_create: %s", hipGetErrorString(e));
+	if (!rc && kind == 0) rc = context_create_impl(device, &c->staticCtx, 2, c);
+	if (rc) {
+		const std::string keep = g_err;
 		vkr_context_destroy(c);
+		snprintf(g_err, sizeof g_err, "%s", keep.c_str());
 		return rc;
 	}
 	*out = c;
 	return VKR_OK;
+}
+
+extern "C" int vkr_context_create(int device, vkr_context** out)
+{
+	if (!out) return set_error(VKR_E_INVALID, "vkr_context_create: out is NULL");
+	return guarded("vkr_context_create", [&] { return context_create_impl(device, out, 0, nullptr); });
 }
 
 extern "C" void vkr_context_destroy(vkr_context* c)
@@ -473,20 +555,22 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 	for (vkr_context* l : c->lanes) vkr_context_destroy(l);
 	c->lanes.clear();
 	if (c->shadowHelper) { c->shadowHelper->hStatus = nullptr; vkr_context_destroy(c->shadowHelper); c->shadowHelper = nullptr; }
-	if (c->evFork) (void)hipEventDestroy(c->evFork);
-	if (c->evJoin) (void)hipEventDestroy(c->evJoin);
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf* bufs[] = { &c->clip, &c->planes, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->bigQueue, &c->zeroSets, &c->tileOffset, &c->cursor, &c->tileFlags, &c->binList,
-		&c->binKeys, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
-		&c->colour2, &c->stencil, &c->mip, &c->shadow };
+	if (c->staticCtx) { vkr_context_destroy(c->staticCtx); c->staticCtx = nullptr; }
+	if (c->evFork) (void)hipEventDestroy(c->evFork);
+	if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+	DevBuf* bufs[VKR_CTX_NBUFS];
+	ctx_bufs(c, bufs);
 	for (DevBuf* b : bufs) b->release();
 	for (auto& t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (auto e : c->eventPool) (void)hipEventDestroy(e);
 	if (c->hStatus) (void)hipHostFree(c->hStatus);
-	if (c->dDecode) (void)hipFree(c->dDecode);
-	if (c->dThresh) (void)hipFree(c->dThresh);
-	if (c->stream) (void)hipStreamDestroy(c->stream);
+	if (!c->isStatic) { // the allocation-free context borrows its owner's tables and stream
+		if (c->dDecode) (void)hipFree(c->dDecode);
+		if (c->dThresh) (void)hipFree(c->dThresh);
+		if (c->stream) (void)hipStreamDestroy(c->stream);
+	}
 	delete c;
 }
 
@@ -507,6 +591,7 @@ struct StageTimer {
 	vkr_context* c; Timed t; bool on;
 	StageTimer(vkr_context* ctx, int stage) : c(ctx), on(ctx->profiling == 1 || (ctx->profiling == 2 && (stage == ST_DEFERRED_LIGHT || stage == ST_RESOLVE_LIGHT)))
 	{
+		if (ctx->isStatic) on = false; // allocation-free frames create no events
 		if (!on) return;
 		t.stage = stage; t.a = get_event(c); t.b = get_event(c);
 		if (!t.a || !t.b) {
@@ -886,6 +971,7 @@ static ViewDev make_view(uint32_t W, uint32_t H, uint32_t x0, uint32_t y0, uint3
 static int ensure_status(vkr_context* c, uint32_t need)
 {
 	if (c->statusUsed + need <= c->statusCap) return VKR_OK;
+	if (c->isStatic) return set_error(VKR_E_LIMIT, "vkr_render_static: %d frames are pending, call vkr_wait first", VKR_STATIC_MAX_PENDING);
 	// only grows while nothing is pending
 	if (!c->pending.empty()) return set_error(VKR_E_LIMIT, "too many frames in flight without vkr_wait (%zu)", c->pending.size());
 	uint32_t cap = c->statusCap ? c->statusCap * 2 : 4096;
@@ -1015,10 +1101,12 @@ static int run_shadow(vkr_context* c, const vkr_scene* s, const vkr_frame_params
 static int run_shadow_beside(vkr_context* c, const vkr_scene* s, const vkr_frame_params& fp, uint32_t statusSlot)
 {
 	int rc;
+	// allocation-free frames have no helper context to create: the light's pass runs on the frame's own stream, with
+	// the frame's own scratch, in front of the camera's passes
+	if (c->isStatic) return run_shadow(c, s, fp, statusSlot);
 	vkr_context* h = c->shadowHelper;
 	if (!h) {
-		if ((rc = vkr_context_create(c->device, &h))) return rc;
-		h->parent = c;
+		if ((rc = context_create_impl(c->device, &h, 1, c))) return rc;
 		c->shadowHelper = h;
 		HIP_CHECK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
 		HIP_CHECK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
@@ -1034,8 +1122,12 @@ static int run_shadow_beside(vkr_context* c, const vkr_scene* s, const vkr_frame
 	return VKR_OK;
 }
 
+// the context that holds the shadow map rendered by run_shadow_beside
+static vkr_context* shadow_owner(vkr_context* c) { return c->isStatic ? c : c->shadowHelper; }
+
 static int join_shadow(vkr_context* c)
 {
+	if (c->isStatic) return VKR_OK; // same stream: already ordered
 	HIP_CHECK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
 	return VKR_OK;
 }
@@ -1047,7 +1139,7 @@ static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 	const uint32_t S = fp.shadow_size ? fp.shadow_size : 2048;
 	int rc;
 	if ((rc = run_shadow_beside(c, s, fp, statusSlot))) return rc;
-	vkr_context* h = c->shadowHelper;
+	vkr_context* h = shadow_owner(c);
 	const size_t n = (size_t)(view.x1 - view.x0) * (view.y1 - view.y0);
 	if ((rc = c->vis.ensure(n * 8))) return rc;
 	if ((rc = c->depth.ensure(n * 4))) return rc;
@@ -1188,7 +1280,7 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 		if ((rc = copy_out(c, rgbaCopy, c->colour.p, n * 4)) || (rc = copy_out(c, out.tri_id, c->triId.p, n * 4)) ||
 		    (rc = copy_out(c, out.depth_bits, c->depth.p, n * 4)) || (rc = copy_out(c, out.gbuf_normal, c->gN.p, n * 8)) ||
 		    (rc = copy_out(c, out.gbuf_albedo, c->gA.p, n * 8))) return rc;
-		if ((fp.flags & VKR_FRAME_SHADOW_PASS) && (rc = copy_out(c, out.shadow_map, c->shadowHelper->shadow.p, (size_t)S * S * 4))) return rc;
+		if ((fp.flags & VKR_FRAME_SHADOW_PASS) && (rc = copy_out(c, out.shadow_map, shadow_owner(c)->shadow.p, (size_t)S * S * 4))) return rc;
 	} else if (!fp.mosaicEffect && dbg == 1) {
 		// ---- forward + shadow map (main/main.cpp:3948-4079)
 		if ((rc = run_forward(c, s, fp, view, colourDst, statusSlot, &out, true))) return rc;
@@ -1286,7 +1378,8 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 // streams and make the next pass start from freshly zeroed sets.
 static void recover_failed_submit(vkr_context* c)
 {
-	const std::string keep = g_err; // the caller reports the submit's error, not the clean-up's
+	char keep[sizeof g_err]; // the caller reports the submit's error, not the clean-up's
+	memcpy(keep, g_err, sizeof keep);
 	(void)hipStreamSynchronize(c->stream);
 	if (c->shadowHelper) {
 		(void)hipStreamSynchronize(c->shadowHelper->stream);
@@ -1294,7 +1387,7 @@ static void recover_failed_submit(vkr_context* c)
 	}
 	c->zeroCapTiles = 0; // run_geometry re-zeroes both sets
 	(void)hipGetLastError();
-	snprintf(g_err, sizeof g_err, "%s", keep.c_str());
+	memcpy(g_err, keep, sizeof keep);
 }
 
 static int render_impl(vkr_context* c, const vkr_scene* s, const vkr_frame_params* fp, const vkr_frame_out* out)
@@ -1319,9 +1412,55 @@ static int render_impl(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 	return VKR_OK;
 }
 
+// vkr_render_static: the frame goes to the context's allocation-free twin.  Every device buffer is cut anew from the
+// static scratch array (the previous frame's slices are dead by then: same stream), the counter sets are zeroed by a
+// memset on that address, nothing is created, grown or freed.
+static int render_static_impl(vkr_context* c, const vkr_scene* s, const vkr_frame_params* fp, const vkr_frame_out* out)
+{
+	if (!c || !s || !fp || !out) return set_error(VKR_E_INVALID, "vkr_render_static: NULL argument");
+	if (c->parent || !c->staticCtx) return set_error(VKR_E_INVALID, "vkr_render_static: not a context created by vkr_context_create");
+	if (s->ctx != c) return set_error(VKR_E_INVALID, "vkr_render_static: scene belongs to another context");
+	vkr_context* t = c->staticCtx;
+	HIP_CHECK(hipSetDevice(c->device));
+	if (t->pending.size() >= VKR_STATIC_MAX_PENDING)
+		return set_error(VKR_E_LIMIT, "vkr_render_static: %d frames are pending, call vkr_wait first", VKR_STATIC_MAX_PENDING);
+	DevBuf* b[VKR_CTX_NBUFS];
+	ctx_bufs(t, b);
+	for (DevBuf* d : b) { d->p = nullptr; d->cap = 0; }
+	t->arena.used = 0;
+	t->capScale = c->capScale; t->binFloor = c->binFloor; // what vkr_render has learnt about this scene's bins
+	t->zeroCapTiles = 0; // the counter sets are re-cut and zeroed for this frame (the array keeps the last frame's contents)
+	int rc;
+	if ((rc = ensure_status(t, 2))) return rc;
+	PendingFrame pf;
+	pf.scene = s; pf.params = *fp; pf.out = *out; pf.statusSlot = t->statusUsed; pf.nPasses = 0;
+	memset(&t->hStatus[pf.statusSlot], 0, sizeof(PassStatus) * 2);
+	if ((rc = submit_frame(t, s, pf.params, pf.out, pf.statusSlot, &pf.nPasses))) { recover_failed_submit(t); return rc; }
+	t->statusUsed += 2;
+	t->pending.push_back(pf); // capacity reserved at creation
+	return VKR_OK;
+}
+
+// the fence for allocation-free frames: nothing can be grown, so a pass that ran out of room is an error
+static int wait_static(vkr_context* t)
+{
+	HIP_CHECK(hipSetDevice(t->device));
+	HIP_CHECK(hipStreamSynchronize(t->stream));
+	int rc = VKR_OK;
+	for (auto& pf : t->pending)
+		for (uint32_t k = 0; k < pf.nPasses; k++)
+			if (t->hStatus[pf.statusSlot + k].overflow)
+				rc = set_error(VKR_E_LIMIT, "vkr_render_static: a pass needs %u bin entries, more than its share of the static scratch holds; "
+				                            "the frame is incomplete, render it with vkr_render", t->hStatus[pf.statusSlot + k].binTotal);
+	t->pending.clear();
+	t->statusUsed = 0;
+	return rc;
+}
+
 static int wait_impl(vkr_context* c)
 {
 	if (!c) return set_error(VKR_E_INVALID, "vkr_wait: NULL context");
+	if (c->isStatic) return wait_static(c);
 	HIP_CHECK(hipSetDevice(c->device));
 	HIP_CHECK(hipStreamSynchronize(c->stream));
 	// stage timers are folded into the totals at every fence, so their events return to the pool however long the
@@ -1373,15 +1512,26 @@ extern "C" int vkr_render(vkr_context* c, const vkr_scene* s, const vkr_frame_pa
 {
 	return guarded("vkr_render", [&] { return render_impl(c, s, fp, out); });
 }
+extern "C" int vkr_render_static(vkr_context* c, const vkr_scene* s, const vkr_frame_params* fp, const vkr_frame_out* out)
+{
+	// no guard: nothing on this path allocates on the host either (the pending list's capacity was reserved when the
+	// context was created), so there is no exception to catch
+	return render_static_impl(c, s, fp, out);
+}
 extern "C" int vkr_wait(vkr_context* c)
 {
 	return guarded("vkr_wait", [&] {
 		int rc = wait_impl(c);
-		if (c)
+		if (c) {
 			for (vkr_context* l : c->lanes) {
 				const int r = wait_impl(l);
 				if (r && !rc) rc = r;
 			}
+			if (c->staticCtx) {
+				const int r = wait_impl(c->staticCtx);
+				if (r && !rc) rc = r;
+			}
+		}
 		return rc;
 	});
 }
@@ -1405,9 +1555,8 @@ static int set_lanes_impl(vkr_context* c, uint32_t n)
 	c->lanes.reserve(n);
 	while (c->lanes.size() + 1 < n) {
 		vkr_context* l = nullptr;
-		int rc = vkr_context_create(c->device, &l);
+		int rc = context_create_impl(c->device, &l, 1, c);
 		if (rc) return rc;
-		l->parent = c;
 		l->profiling = c->profiling;
 		c->lanes.push_back(l);
 	}

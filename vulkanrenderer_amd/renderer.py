@@ -24,7 +24,7 @@ EXPORTS = [
     "vkr_context_stream", "vkr_decode_png_file", "vkr_free", "vkr_write_png_file",
     "vkr_user_state_init", "vkr_update_user_state", "vkr_context_set_frames_in_flight",
     "vkr_wait_next_lane", "vkr_user_state_key", "vkr_user_state_button", "vkr_user_state_motion",
-    "vkr_frame_params_set_modes",
+    "vkr_frame_params_set_modes", "vkr_render_static",
 ]
 
 
@@ -50,6 +50,7 @@ def lib():
         L.vkr_scene_read_texture_level.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.vkr_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.FrameParams), C.POINTER(abi.FrameOut)]
+        L.vkr_render_static.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.FrameParams), C.POINTER(abi.FrameOut)]
         L.vkr_wait.argtypes = [C.c_void_p]
         L.vkr_update_scene_uniforms.argtypes = [C.POINTER(abi.SceneUniform), C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
         L.vkr_update_scene_uniforms.restype = None
@@ -279,7 +280,11 @@ class Scene:
         """Asynchronous vkr_render with a caller-built FrameOut (host or device pointers)."""
         _check(lib().vkr_render(self.ctx.h, self.h, C.byref(params), C.byref(out)))
 
-    def render(self, params, want=SIDE):
+    def submit_static(self, params, out):
+        """vkr_render_static: the allocation-free variant (device buffers from the library's static scratch array)."""
+        _check(lib().vkr_render_static(self.ctx.h, self.h, C.byref(params), C.byref(out)))
+
+    def render(self, params, want=SIDE, static=False):
         """Renders one frame into fresh numpy arrays and waits for it."""
         W, H = params.width, params.height
         x0, y0, x1, y1 = params.rect_x0, params.rect_y0, params.rect_x1, params.rect_y1
@@ -299,6 +304,6 @@ class Scene:
         for k, v in bufs.items():
             if k in want:
                 setattr(out, k, v.ctypes.data)
-        self.submit(params, out)
+        (self.submit_static if static else self.submit)(params, out)
         self.ctx.wait()
         return {k: v for k, v in bufs.items() if k in want}
