@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: deferred shading with all 21 brazier lights of the
-SunTemple-proxy scene, whole frames (transform, setup, binning, rasterise,
-G-buffer resolve, lighting), output left in device memory.
+SunTemple-proxy scene at 3840x2160, whole frames (transform, setup, binning,
+rasterise, G-buffer resolve, lighting), output left in device memory.
 
   python bench.py --gpus N --steps K --warmup W
 
-A step is one frame for one camera pose.  With N > 1 (launched through
-torch.distributed.run, one rank per GPU) the camera poses of a fly-through are
-partitioned over the ranks (scene replicated per GPU, no data-path
-collective), so per-GPU work is fixed: weak scaling.  `--partition sortfirst`
-instead splits every frame into N horizontal bands and gathers them on rank 0
-over RCCL (strong scaling).
+A step is one frame for one camera pose.  With N > 1 there is one process per
+GPU: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in
+the environment), or - when those are absent - started by this script itself,
+which then only waits for its N children (the parent never touches a GPU).
+By default the camera poses of a fly-through are partitioned over the ranks
+(scene replicated per GPU, no data-path collective), so per-GPU work is fixed:
+weak scaling.  `--partition sortfirst` instead gives every rank a share of the
+rows of every frame (bands, or interleaved stripes with --stripe-height) and
+gathers them on rank 0 over RCCL inside the renderer library (strong scaling).
 
-Rank 0 prints one JSON line.
+`--config 1..5` selects the other BASELINE.json workloads.  The K timed steps
+are repeated `--repeats` times; ms_per_step is the median repeat, min and max
+are printed beside it.  Rank 0 prints one JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,11 +33,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E peak
 FUSED_BYTES_PER_PIXEL = 12   # k_resolve_light: 8 (visibility buffer) read + 4 (RGBA8) written; texels and per-triangle data excluded
 LIGHT_BYTES_PER_PIXEL = 24   # 8 (normal+metal RGBA16F) + 8 (albedo+rough RGBA16F) + 4 (D32) read + 4 (RGBA8) written
+IDENTITY = [1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+
+PRESETS = {
+    # BASELINE.json's five configurations
+    1: dict(mode="forward", width=1280, height=720, pose="identity", shadow=2048,
+            name="config 1: forward + single-light 2048^2 shadow map, 1280x720, fixed camera (the reference's start pose)"),
+    2: dict(mode="deferred", width=1920, height=1080, name="config 2: deferred shading, 21 brazier lights, 1920x1080"),
+    3: dict(mode="views", width=1920, height=1080,
+            name="config 3: debug views at 1920x1080 (mip level, linearised depth, depth derivatives, overdraw, overshading), one view per frame in turn"),
+    4: dict(mode="deferred", width=3840, height=2160, shadow=4096, partition="sortfirst",
+            name="config 4: deferred + 4096^2 light depth pass at 3840x2160, sort-first rows across the GPUs with RCCL gather"),
+    5: dict(mode="mosaic", width=1920, height=1080, steps=64,
+            name="config 5: 512-pose fly-through at 1920x1080, forward + mosaic post-process, poses partitioned over the GPUs"),
+}
+VIEWS = (2, 3, 4, 5, 6)
 
 
 def fly_pose(i, n=512):
@@ -42,12 +62,12 @@ def fly_pose(i, n=512):
     return [c, 0.0, -s, 0.0, 0.0, 1.0, 0.0, 0.0, s, 0.0, c, 0.0, 0.0, -1.0, tz, 1.0]
 
 
-def measured_traffic(width, height, kernel="k_deferred_light"):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*pmc_traffic*.json) taken at
-    this extent, or None.  PMC counters need their own rocprofv3 passes, so they cannot be collected inside this run."""
+def newest_profile(pattern, width, height, kernel, key):
+    """Value `key` of `kernel` from the newest committed PMC summary (profiles/<pattern>) taken at this extent, or None.
+    PMC counters need their own rocprofv3 passes, so they cannot be collected inside this run."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         try:
             with open(path) as f:
                 j = json.load(f)
@@ -56,43 +76,29 @@ def measured_traffic(width, height, kernel="k_deferred_light"):
         if j.get("width") != width or j.get("height") != height:
             continue
         for name, k in j.get("kernels", {}).items():
-            if name.startswith(kernel) and "hbm_bytes_per_launch_corrected" in k:
-                best = (int(k["hbm_bytes_per_launch_corrected"]), os.path.basename(path))
+            if name.startswith(kernel) and key in k:
+                best = (k[key], os.path.basename(path))
     return best
 
 
-def measured_valu_busy(width, height, kernel="k_deferred_light"):
-    """Vector-ALU busy fraction of `kernel` from the newest committed PMC summary (profiles/*pmc_valu*.json) taken at this
-    extent, or None: the lighting kernel is bound by ALU issue, so this is reported beside the HBM fraction."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_valu*.json"))):
-        try:
-            with open(path) as f:
-                j = json.load(f)
-        except (OSError, ValueError):
-            continue
-        if j.get("width") != width or j.get("height") != height:
-            continue
-        for name, k in j.get("kernels", {}).items():
-            if name.startswith(kernel) and "valu_busy_frac" in k:
-                best = (min(1.0, float(k["valu_busy_frac"])), os.path.basename(path))
-    return best
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames per repeat and rank (default 64)")
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--mode", default="deferred", choices=["deferred", "forward", "mosaic"])
-    ap.add_argument("--partition", default="poses", choices=["poses", "sortfirst"])
+    ap.add_argument("--repeats", type=int, default=5, help="the timed region of --steps frames is run this many times; median / min / max are reported")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5], help="one of BASELINE.json's five configurations (0 = the headline: deferred 4K)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--mode", default=None, choices=["deferred", "forward", "mosaic", "views"])
+    ap.add_argument("--pose", default=None, choices=["fly", "identity"], help="fly: a different fly-through pose every frame; identity: the reference's start pose")
+    ap.add_argument("--partition", default=None, choices=["poses", "sortfirst"])
+    ap.add_argument("--stripe-height", type=int, default=0,
+                    help="sort-first: 0 = horizontal bands; N (a multiple of 32) = interleaved stripes of N rows, which balance clustered foliage better")
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--tex-size", type=int, default=1024)
-    ap.add_argument("--shadow", type=int, default=0,
-                    help="deferred mode: also render an N x N light depth map per frame (the 'deferred + shadow map' stress composition)")
+    ap.add_argument("--shadow", type=int, default=None,
+                    help="deferred mode: also render an N x N light depth map per frame (the 'deferred + shadow map' stress composition); forward / mosaic: the map's size")
     ap.add_argument("--fused", action="store_true",
                     help="deferred mode: G-buffer resolve and lighting as one kernel (VKR_FRAME_FUSED_LIGHTING); the roofline "
                          "object then describes k_resolve_light with 12 B/pixel (8 read from the visibility buffer, 4 written)")
@@ -103,32 +109,154 @@ def main():
                     help="deliver every frame into host memory (the PCIe-inclusive rate; the headline value keeps frames in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs, collectives on host tensors)")
+                    help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs, rows gathered through host tensors)")
     ap.add_argument("--profile-all", action="store_true", help="time every stage with HIP events (adds host overhead)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    preset = PRESETS.get(args.config, {})
+    for key, default in (("mode", "deferred"), ("width", 3840), ("height", 2160), ("pose", "fly"), ("partition", "poses"), ("shadow", 0), ("steps", 64)):
+        if getattr(args, key) is None:
+            setattr(args, key, preset.get(key, default))
+    if args.config == 5 and "--steps" not in (argv if argv is not None else sys.argv):
+        args.steps = max(1, 512 // max(1, args.gpus))  # the 512 poses of the fly-through, once per repeat
+    args.preset_name = preset.get("name")
+    return args
 
+
+def launch_children(args, argv):
+    """`--gpus N` without a launcher: start N copies of this script, one per GPU, as fresh child processes (this
+    parent has not touched a GPU and does not), wait for them, pass rank 0's line through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def host_physical_cores():
+    """(physical cores of the machine, logical CPUs this process may run on)."""
+    cores = set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return (len(cores) or None), usable
+
+
+def cpu_baseline(packed, params_for, W, H, mode_name, scene, np):
+    """The CPU restatement timed on this machine's host cores: the oracle file compiled here with -O3 -march=native and
+    OpenMP over bands of rows (oracle/Makefile target `native`; timing only - the checker stays the -O2 build), one
+    warm-up frame + five timed frames of pose 0, median.  Threads: what OpenMP gives this job (OMP_NUM_THREADS, 16 on a
+    one-GPU box), and once more with 8 for comparison across machines."""
+    from vulkanrenderer_amd import abi, renderer
+    from oracle import oracle
+    phys, usable = host_physical_cores()
+    native = os.path.join(ROOT, "oracle", "_build", "libvkr_oracle_native.so")
+    built = subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 0
+    p = params_for(0, oracle.make_uniforms)
+    res = {}
+    if built and os.path.exists(native):
+        L = C.CDLL(native)
+        L.ora_scene_create.restype = C.c_void_p
+        L.ora_scene_create.argtypes = [C.POINTER(abi.SceneDesc)]
+        L.ora_scene_destroy.argtypes = [C.c_void_p]
+        L.ora_render_bands.argtypes = [C.c_void_p, C.POINTER(abi.FrameParams), C.POINTER(abi.FrameOut), C.c_uint32]
+        L.ora_set_band_threads.argtypes = [C.c_int]
+        h = L.ora_scene_create(C.byref(packed.desc))
+        img = np.zeros((H, W, 4), np.uint8)
+        fo = abi.FrameOut()
+        fo.rgba8 = img.ctypes.data
+        if p.flags & abi.FRAME_SHADOW_PASS:  # the composition with a light depth pass: the CPU draws that pass as well
+            S = p.shadow_size or 2048
+            smap = np.zeros((S, S), np.float32)
+            fo.shadow_map = smap.ctypes.data
+        omp = L.ora_band_threads()
+        for threads in sorted({min(omp, usable), min(8, omp, usable)}, reverse=True):
+            L.ora_set_band_threads(threads)
+            band = max(32, -(-H // (2 * threads)))
+            times = []
+            for i in range(6 if threads == min(omp, usable) else 4):
+                t0 = time.perf_counter()
+                rc = L.ora_render_bands(h, C.byref(p), C.byref(fo), band)
+                times.append(time.perf_counter() - t0)
+                assert rc == 0
+            times = sorted(times[1:])  # the first frame is the warm-up
+            res[threads] = times[len(times) // 2]
+        L.ora_scene_destroy(h)
+        ref = img
+        build = "-O3 -march=native -fopenmp, built on this machine"
+    else:
+        # no compiler here: the -O2 checker build, bands over a Python thread pool
+        threads = min(16, usable)
+        osc = oracle.OracleScene(packed)
+        t0 = time.perf_counter()
+        ref = osc.render(p, want=("rgba8",), threads=threads)["rgba8"]
+        res[threads] = time.perf_counter() - t0
+        osc.close()
+        build = "-O2 (no compiler on this machine for the timing build), one frame"
+    top = max(res)
+    # the oracle frame doubles as a check of the frame the GPU path produces for the same pose
+    got = scene.render(params_for(0, renderer.make_uniforms), want=("rgba8",))["rgba8"]
+    diff = np.abs(ref.astype(np.int32) - got.astype(np.int32))
+    mse = float(np.mean(diff.astype(np.float64) ** 2))
+    out = {"value": round(W * H / res[top] / 1e6, 4), "unit": "Mpix/s", "cores": top, "kind": "port",
+           "sample": "pose 0 of the same workload (%dx%d %s) by the CPU restatement oracle/vkr_oracle.c (%s), OpenMP over bands of rows, "
+                     "1 warm-up + 5 timed frames, median %.2f s per frame" % (W, H, mode_name, build, res[top]),
+           "host_physical_cores": phys, "host_usable_cpus": usable,
+           "gpu_frame_vs_oracle": {"max_abs_diff_8bit": int(diff.max()), "psnr_db": (99.0 if mse == 0 else round(10 * math.log10(255.0 ** 2 / mse), 1))}}
+    for t, dt in res.items():
+        if t != top:
+            out["value_at_%d_threads" % t] = round(W * H / dt / 1e6, 4)
+    return out
+
+
+def run(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
+            if local_rank >= ndev:
+                raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible); use --backend gloo to rehearse with shared GPUs" % (rank, ndev))
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
-            local_rank %= max(1, torch.cuda.device_count())
-    if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
-        args.gpus = world
+            local_rank %= ndev
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; running %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from vulkanrenderer_amd import abi, renderer, scenes
+    from vulkanrenderer_amd.dist import HostCompositor, RcclCompositor
 
     W, H = args.width, args.height
     t0 = time.time()
@@ -138,24 +266,34 @@ def main():
     stats = scene.stats()
     t_scene = time.time() - t0
 
-    from vulkanrenderer_amd.dist import BandCompositor
-
-    kw = dict(deferred=(args.mode == "deferred"), mosaic=(args.mode == "mosaic"), debug=1)
-    if args.shadow and args.mode == "deferred":
-        kw.update(shadow_size=args.shadow, flags=abi.FRAME_SHADOW_PASS)
+    base_kw = dict(deferred=(args.mode == "deferred"), mosaic=(args.mode == "mosaic"), debug=1)
+    if args.shadow:
+        base_kw["shadow_size"] = args.shadow
+        if args.mode == "deferred":
+            base_kw["flags"] = abi.FRAME_SHADOW_PASS
     if args.fused and args.mode == "deferred":
-        kw["flags"] = kw.get("flags", 0) | abi.FRAME_FUSED_LIGHTING
+        base_kw["flags"] = base_kw.get("flags", 0) | abi.FRAME_FUSED_LIGHTING
     sortfirst = args.partition == "sortfirst" and world > 1
-    comp = None
+    stripe_h = args.stripe_height if sortfirst else 0
+    if sortfirst and args.mode == "mosaic" and stripe_h:
+        raise SystemExit("bench.py: the mosaic pass is not rendered in stripes; use bands")
+    comp, rect, stripes = None, None, 0
     if sortfirst:
-        comp = BandCompositor(W, H, dev, rank, world, host_collective=(args.backend == "gloo"))
-        rect = comp.rect
+        if args.backend == "nccl":
+            comp = RcclCompositor(ctx, W, H, rank, world, dev, stripe_height=stripe_h)
+        else:
+            comp = HostCompositor(W, H, dev, rank, world, stripe_height=stripe_h)
         out_t = comp.local
+        my_rows = comp.my_rows
+        if stripe_h:
+            stripes = abi.stripes(stripe_h, world, rank)
+        else:
+            first = renderer.sortfirst_rows(H, world, rank, 0)[0]
+            rect = (0, first, W, first + my_rows)
     else:
-        rect = None
         out_t = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
-    rh = (rect[3] - rect[1]) if rect else H
-    lanes = 1 if sortfirst else max(1, args.lanes)  # sort-first gathers after every frame: nothing to overlap with
+        my_rows = H
+    lanes = 1 if sortfirst else max(1, args.lanes)  # sort-first gathers after every frame on the frame's own stream
     ctx.set_frames_in_flight(lanes)
     # one output image per lane, as a swapchain has one image per frame in flight
     outs = [out_t] + [torch.empty_like(out_t) for _ in range(lanes - 1)]
@@ -167,16 +305,26 @@ def main():
         fo.rgba8 = o.data_ptr()
         fos.append(fo)
 
+    def params_for(frame_index, make_uniforms, whole=False):
+        """Parameters of the frame this rank renders at step `frame_index` (whole: without this rank's row partition)."""
+        pose_index = frame_index if sortfirst else (frame_index * world + rank)
+        pose = IDENTITY if args.pose == "identity" else fly_pose(pose_index % 512)
+        kw = dict(base_kw)
+        if args.mode == "views":
+            kw["debug"] = VIEWS[pose_index % len(VIEWS)]
+        u = make_uniforms(W, H, pose, kw["debug"])
+        if whole:
+            return abi.make_params(W, H, u, **kw)
+        return abi.make_params(W, H, u, rect=rect, stripes=stripes, **kw)
+
     def frame(i):
-        # poses: frame i of the fly-through goes to rank i % world; sort-first: every rank renders its band of frame i
-        pose_index = i if sortfirst else (i * world + rank)
-        u = renderer.make_uniforms(W, H, fly_pose(pose_index % 512), 1)
-        p = abi.make_params(W, H, u, rect=rect, **kw)
-        if rh > 0:
-            scene.submit(p, fos[i % lanes])
+        # poses: frame i of the fly-through goes to rank i % world; sort-first: every rank renders its rows of frame i
+        if my_rows > 0:
+            scene.submit(params_for(i, renderer.make_uniforms), fos[i % lanes])
         if sortfirst:
-            ctx.wait()  # the band must be complete before RCCL reads it on torch's stream
-            comp.gather()
+            if args.backend != "nccl":
+                ctx.wait()  # the host-tensor rehearsal reads the rows on another stream
+            comp.gather()   # RCCL: queued on the renderer's stream behind the frame, no host wait
 
     def barrier():
         ctx.wait()
@@ -190,18 +338,25 @@ def main():
     barrier()
     ctx.profile(True)
     renderer._check(renderer.lib().vkr_profile_enable(ctx.h, 1 if args.profile_all else 2))
-    barrier()
-    t_start = time.perf_counter()
-    for i in range(args.steps):
-        frame(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    per_repeat = []
+    step = args.warmup
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t_start = time.perf_counter()
+        for i in range(args.steps):
+            frame(step + i)
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        step += args.steps
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        per_repeat.append(elapsed)
     report = ctx.profile_report()
     renderer._check(renderer.lib().vkr_profile_enable(ctx.h, 0))
+    ranked = sorted(per_repeat)
+    elapsed = ranked[len(ranked) // 2]  # median repeat
 
     frames_total = args.steps * (1 if sortfirst else world)
     pixels_total = frames_total * W * H
@@ -211,7 +366,7 @@ def main():
     fusedk = report.get("k_resolve_light")
     if fusedk and fusedk[1]:
         avg_ms = fusedk[0] / fusedk[1]
-        nbytes = FUSED_BYTES_PER_PIXEL * W * rh
+        nbytes = FUSED_BYTES_PER_PIXEL * W * my_rows
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "k_resolve_light",
@@ -220,43 +375,29 @@ def main():
     light = report.get("k_deferred_light")
     if light and light[1]:
         avg_ms = light[0] / light[1]
-        launch_pixels = W * rh
+        launch_pixels = W * my_rows
         achieved = LIGHT_BYTES_PER_PIXEL * launch_pixels / (avg_ms * 1e-3) / 1e9
-        traffic = measured_traffic(W, rh) if args.mode == "deferred" else None
+        traffic = newest_profile("*pmc_traffic*.json", W, my_rows, "k_deferred_light", "hbm_bytes_per_launch_corrected") if args.mode == "deferred" else None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic[0] if traffic else None,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(traffic[0]) if traffic else None,
                     "traffic_source": ("profiles/" + traffic[1]) if traffic else None, "kernel": "k_deferred_light",
-                    "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": LIGHT_BYTES_PER_PIXEL * launch_pixels}
-        valu = measured_valu_busy(W, rh) if args.mode == "deferred" else None
-        if valu:
-            roofline["valu_busy_frac"] = valu[0]
-            roofline["valu_busy_source"] = "profiles/" + valu[1]
+                    "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": LIGHT_BYTES_PER_PIXEL * launch_pixels,
+                    # the fraction is measured against the HBM roofline, which is the graded number; what actually limits the
+                    # kernel is vector-ALU issue (21 BRDF evaluations per pixel), see valu_issue_frac
+                    "limited_by": "valu-issue"}
+        issue = newest_profile("*pmc_valu*.json", W, my_rows, "k_deferred_light", "valu_issue_frac") if args.mode == "deferred" else None
+        if issue:
+            roofline["valu_issue_frac"] = round(float(issue[0]), 4)  # VALU instructions x 2 cycles / (SIMDs x kernel cycles), not clamped
+            roofline["valu_issue_source"] = "profiles/" + issue[1]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle
-        osc = oracle.OracleScene(packed)
-        u = oracle.make_uniforms(W, H, fly_pose(0), 1)
-        p = abi.make_params(W, H, u, **kw)
-        # the box gives one GPU's job 16 cores (os.cpu_count() reports the whole machine)
-        try:
-            cores = min(16, len(os.sched_getaffinity(0)))
-        except AttributeError:
-            cores = min(16, os.cpu_count() or 1)
-        tc = time.perf_counter()
-        ref = osc.render(p, want=("rgba8",), threads=cores)["rgba8"]
-        dt = time.perf_counter() - tc
-        # the oracle frame doubles as a check of the frame the GPU path produces for the same pose
-        got = scene.render(abi.make_params(W, H, renderer.make_uniforms(W, H, fly_pose(0), 1), **kw), want=("rgba8",))["rgba8"]
-        diff = np.abs(ref.astype(np.int32) - got.astype(np.int32))
-        mse = float(np.mean(diff.astype(np.float64) ** 2))
-        cpu = {"value": round(W * H / dt / 1e6, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
-               "sample": "1 frame of the same workload (pose 0, %dx%d %s) by the CPU restatement oracle/vkr_oracle.c, %d threads over horizontal bands, %.1f s"
-                         % (W, H, args.mode, cores, dt),
-               "gpu_frame_vs_oracle": {"max_abs_diff_8bit": int(diff.max()), "psnr_db": (99.0 if mse == 0 else round(10 * math.log10(255.0 ** 2 / mse), 1))}}
-        osc.close()
+        cpu = cpu_baseline(packed, lambda i, mk: params_for(i, mk, whole=True), W, H, args.mode, scene, np)
 
     if rank == 0:
+        workload = args.preset_name or ("SunTemple-proxy v1 %s shading, 21 brazier lights, %dx%d, %s, whole frame%s" % (
+            args.mode, W, H, "fly-through poses" if args.pose == "fly" else "fixed camera",
+            (" + %dx%d light depth map" % (args.shadow, args.shadow)) if (args.shadow and args.mode == "deferred") else ""))
         line = {
             "metric": "Mpix/s (frames/s) Sun Temple deferred 4K at 1/2/4/8 GPUs; % HBM roofline",
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -264,19 +405,32 @@ def main():
             "scaling": "strong" if sortfirst else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "frames_per_s": round(frames_total / elapsed, 2),
-            "config": {"workload": "SunTemple-proxy v1 %s shading, 21 brazier lights, %dx%d, fly-through poses, whole frame%s" % (
-                args.mode, W, H, (" + %dx%d light depth map" % (args.shadow, args.shadow)) if (args.shadow and args.mode == "deferred") else ""),
+            "repeats": len(per_repeat), "ms_per_step_min": round(ranked[0] / args.steps * 1e3, 4),
+            "ms_per_step_max": round(ranked[-1] / args.steps * 1e3, 4),
+            "config": {"workload": workload if args.preset_name is None else "SunTemple-proxy v1, " + workload,
+                       "mode": args.mode, "width": W, "height": H,
                        "triangles": stats["triangles"], "vertices": stats["vertices"], "texture_bytes": stats["texture_bytes"],
-                       "partition": args.partition, "frames_in_flight": lanes, "readback": args.readback, "scene_setup_s": round(t_scene, 1)},
+                       "partition": args.partition if world > 1 else "none", "stripe_height": stripe_h, "backend": args.backend if world > 1 else None,
+                       "frames_in_flight": lanes, "readback": args.readback, "scene_setup_s": round(t_scene, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if args.profile_all:
             line["stages_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in report.items()}
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    if comp is not None and hasattr(comp, "close"):
+        ctx.wait()
+        comp.close()
     scene.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_children(args, sys.argv[1:]))
+    run(args)
 
 
 if __name__ == "__main__":

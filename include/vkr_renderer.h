@@ -154,9 +154,15 @@ typedef struct vkr_frame_params {
 	 * all four zero = the whole frame.  Output buffers are rectangle-sized. */
 	uint32_t rect_x0, rect_y0, rect_x1, rect_y1;
 	uint32_t flags;
-	uint32_t _pad;
+	/* sort-first by interleaved stripes instead of one rectangle: 0 = off, else VKR_STRIPES(height, count, index): of
+	 * the frame cut into stripes of `height` rows (a multiple of 32), this call renders stripes index, index + count,
+	 * index + 2 count, ... and stores their rows back to back; output buffers hold vkr_sortfirst_rows() rows of the
+	 * full width.  Foliage and other expensive regions are clustered on screen, so interleaved stripes balance the
+	 * ranks better than bands.  Not combined with rect_* or the mosaic pass. */
+	uint32_t stripes;
 	vkr_uniforms uniforms;
 } vkr_frame_params;
+#define VKR_STRIPES(height, count, index) ((uint32_t)(height) | ((uint32_t)(count) << 16) | ((uint32_t)(index) << 24))
 
 /* Output buffers, each (rect width * rect height) elements, row 0 = top,
  * tightly packed, except shadow_map which is shadow_size^2. */
@@ -302,6 +308,32 @@ VKR_API void vkr_frame_params_set_modes(vkr_frame_params* params, const vkr_user
  * x0.05 slow) along the camera's own axes, in the reference's key order. */
 VKR_API void vkr_update_user_state(vkr_user_state* state, float elapsedSeconds);
 
+/* ---- sort-first compositing across the GPUs of a node ---- */
+
+/* The reference presents from the one device it renders on (main/main.cpp:1391-1405, utils/vulkan_window.cpp:223-255);
+ * when several GPUs share a frame (one process and one context per GPU, scene replicated) each renders its rows and
+ * the rows meet in one grouped RCCL send / receive over xGMI.
+ * Rows of rank `rank` out of `world`: stripe_height 0 = horizontal bands of equal, even height (first_row, row_count);
+ * stripe_height > 0 = stripes dealt round-robin as VKR_STRIPES renders them (first_row = the first stripe's row,
+ * row_count = all of the rank's rows, stored back to back). */
+VKR_API int vkr_sortfirst_rows(uint32_t height, uint32_t world, uint32_t rank, uint32_t stripe_height, uint32_t* first_row,
+                               uint32_t* row_count);
+typedef struct vkr_compositor vkr_compositor;
+#define VKR_COMPOSITE_ID_BYTES 128
+/* One rank creates the id (an ncclUniqueId), the host hands it to the others by whatever channel it has (MPI, a file,
+ * torch.distributed), every rank then creates its compositor: a collective call, like ncclCommInitRank. */
+VKR_API int vkr_composite_unique_id(uint8_t id[VKR_COMPOSITE_ID_BYTES]);
+VKR_API int vkr_compositor_create(vkr_context* ctx, const uint8_t id[VKR_COMPOSITE_ID_BYTES], int rank, int world,
+                                  vkr_compositor** out);
+VKR_API void vkr_compositor_destroy(vkr_compositor* c);
+/* Collective, asynchronous on the context's stream (behind the frames queued there, in front of the next ones; no
+ * host wait, no allocation): `local` = this rank's rows of the width x height RGBA8 frame as vkr_render delivered them
+ * (device memory), `frame` = the whole frame on the receiving rank(s) (device memory; may be NULL elsewhere).
+ * root >= 0: gather to that rank; root < 0: every rank receives the frame.  A band rendered straight into its place
+ * (local == frame + first_row * width * 4) is not copied. */
+VKR_API int vkr_composite_gather(vkr_compositor* c, uint32_t width, uint32_t height, uint32_t stripe_height, const void* local,
+                                 void* frame, int root);
+
 /* ---- measurement ---- */
 
 /* Stage timing with HIP events on the context's stream.  Stage names are
@@ -314,8 +346,9 @@ VKR_API int vkr_stage_count(void);
 VKR_API const char* vkr_stage_name(int stage);
 /* Synchronises, then returns accumulated milliseconds and launch count. */
 VKR_API int vkr_profile_get(vkr_context* ctx, int stage, double* total_ms, uint64_t* launches);
-/* The HIP stream (hipStream_t) the context launches on. */
+/* The HIP stream (hipStream_t) the context launches on, and its device. */
 VKR_API void* vkr_context_stream(vkr_context* ctx);
+VKR_API int vkr_context_device(vkr_context* ctx);
 
 #ifdef __cplusplus
 }

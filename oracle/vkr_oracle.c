@@ -30,6 +30,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORA_API __attribute__((visibility("default")))
 
@@ -1481,6 +1484,41 @@ ORA_API int ora_render_rows(const ora_scene* sc, const vkr_frame_params* fp, con
 	if (out->shadow_map && needShadow) memcpy(out->shadow_map, f.shadow, (size_t)f.S * f.S * 4);
 	free(f.depth); free(f.tri); free(f.rgba); free(f.mip); free(f.stencil); free(f.gN); free(f.gA); free(f.shadow);
 	return 0;
+}
+
+/* One whole frame as bands of band_rows rows.  Compiled with -fopenmp (the timing build of the CPU baseline) the bands
+ * are rendered by an OpenMP team, dynamically scheduled: the cost of a band depends on what it shows.  Without OpenMP the
+ * pragma is ignored and the bands are rendered one after the other.  Same frame either way. */
+ORA_API int ora_render_bands(const ora_scene* sc, const vkr_frame_params* fp, const vkr_frame_out* out, uint32_t band_rows)
+{
+	if (!band_rows) band_rows = 64;
+	const int nb = (int)((fp->height + band_rows - 1) / band_rows);
+	int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : bad)
+	for (int b = 0; b < nb; b++) {
+		const uint32_t y0 = (uint32_t)b * band_rows, y1 = y0 + band_rows;
+		bad |= ora_render_rows(sc, fp, out, y0, y1 < fp->height ? y1 : fp->height);
+	}
+	return bad;
+}
+
+/* threads ora_render_bands will use */
+ORA_API int ora_band_threads(void)
+{
+#ifdef _OPENMP
+	return omp_get_max_threads();
+#else
+	return 1;
+#endif
+}
+
+ORA_API void ora_set_band_threads(int n)
+{
+#ifdef _OPENMP
+	if (n > 0) omp_set_num_threads(n);
+#else
+	(void)n;
+#endif
 }
 
 /* One whole frame. */

@@ -37,3 +37,39 @@ def micro():
 def micro_oracle(micro):
     from oracle import oracle
     return oracle.OracleScene(micro)
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed buffer for tests that hand device pointers to the C ABI, allocated through the HIP runtime the
+    renderer library itself runs on (importing another framework for this could bring a second ROCm installation
+    into the process)."""
+
+    def __init__(self, nbytes):
+        import ctypes as C
+        from vulkanrenderer_amd import renderer
+        renderer.lib()                                 # loads the runtime; the name below then resolves to that copy
+        self._hip = C.CDLL("libamdhip64.so.7")
+        self._hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self._hip.hipFree.argtypes = [C.c_void_p]
+        self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self._hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.nbytes = nbytes
+        p = C.c_void_p()
+        assert self._hip.hipMalloc(C.byref(p), nbytes) == 0
+        self.ptr = p.value
+
+    def zero(self):
+        assert self._hip.hipMemset(self.ptr, 0, self.nbytes) == 0
+        assert self._hip.hipDeviceSynchronize() == 0
+
+    def numpy(self, shape, dtype):
+        import numpy as np
+        out = np.zeros(shape, dtype)
+        assert out.nbytes == self.nbytes
+        assert self._hip.hipMemcpy(out.ctypes.data, self.ptr, self.nbytes, 2) == 0   # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        if self.ptr:
+            self._hip.hipFree(self.ptr)
+            self.ptr = None

@@ -3,6 +3,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -89,3 +90,26 @@ def test_c_host_builds_and_fails_cleanly_without_a_gpu():
     if not torch.cuda.is_available():
         r = subprocess.run([exe, os.path.join(root, "tests", "golden", "micro.comp5892mesh")], capture_output=True, text=True, timeout=120)
         assert r.returncode == 1 and "vkr_context_create" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_sortfirst_rows_partition_the_frame():
+    """vkr_sortfirst_rows (host-only): bands and interleaved stripes give every row of the frame to exactly one rank;
+    bands agree with the Python-side band_rect."""
+    from vulkanrenderer_amd import renderer
+    from vulkanrenderer_amd.dist import band_rect, stripe_rows
+    for height in (2160, 1080, 720, 36, 5):
+        for world in (1, 2, 3, 8):
+            owner = np.zeros(height, np.int32)
+            for r in range(world):
+                first, count = renderer.sortfirst_rows(height, world, r, 0)
+                assert (first, first + count) == band_rect(r, world, 64, height)[1::2]
+                owner[first:first + count] += 1
+            assert np.all(owner == 1)
+            for sh in (32, 64, 128):
+                owner[:] = 0
+                for r in range(world):
+                    first, count = renderer.sortfirst_rows(height, world, r, sh)
+                    rows = stripe_rows(height, world, r, sh)
+                    assert count == len(rows) and (count == 0 or rows[0] == first)
+                    owner[rows] += 1
+                assert np.all(owner == 1)

@@ -55,6 +55,21 @@ def _worker(rank, world, port, full):
                 assert np.array_equal(out.numpy(), img.astype(np.uint8))
             else:
                 assert out is None
+        # interleaved stripes: the rows each rank owns come from the library's own partition function
+        # (vkr_sortfirst_rows, what vkr_render's stripes and the RCCL compositor use), stored back to back
+        from vulkanrenderer_amd import renderer
+        from vulkanrenderer_amd.dist import HostCompositor, stripe_rows
+        for sh in (32, 64):
+            comp = HostCompositor(W, H, "cpu", stripe_height=sh)
+            first, count = renderer.sortfirst_rows(H, world, rank, sh)
+            rows = stripe_rows(H, world, rank, sh)
+            assert count == len(rows) == comp.my_rows and (count == 0 or rows[0] == first)
+            comp.local.zero_()
+            if count:
+                comp.local[:count] = torch.from_numpy(full[rows].astype(np.uint8))
+            out = comp.gather()
+            if rank == 0:
+                assert np.array_equal(out.numpy(), full.astype(np.uint8))
         # every rank gets the frame
         comp = BandCompositor(W, H, "cpu", everywhere=True)
         x0, y0, x1, y1 = comp.rect
@@ -69,7 +84,7 @@ def _worker(rank, world, port, full):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shape", [(36, 64), (37, 20)])
+@pytest.mark.parametrize("shape", [(36, 64), (37, 20), (150, 24)])
 def test_sort_first_gather_world2(shape):
     H, W = shape
     rng = np.random.default_rng(2)

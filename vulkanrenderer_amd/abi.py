@@ -68,7 +68,7 @@ class FrameParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("shadow_size", C.c_uint32),
                 ("debugVisualisation", C.c_int32), ("mosaicEffect", C.c_int32), ("deferredShading", C.c_int32),
                 ("rect_x0", C.c_uint32), ("rect_y0", C.c_uint32), ("rect_x1", C.c_uint32), ("rect_y1", C.c_uint32),
-                ("flags", C.c_uint32), ("_pad", C.c_uint32), ("uniforms", Uniforms)]
+                ("flags", C.c_uint32), ("stripes", C.c_uint32), ("uniforms", Uniforms)]
 
 
 class FrameOut(C.Structure):
@@ -166,9 +166,15 @@ FRAME_SHADOW_PASS = 1  # VKR_FRAME_SHADOW_PASS
 FRAME_FUSED_LIGHTING = 2  # VKR_FRAME_FUSED_LIGHTING
 
 
-def make_params(width, height, uniforms, debug=1, mosaic=False, deferred=False, shadow_size=0, rect=None, flags=0):
+def stripes(height, count, index):
+    """VKR_STRIPES(height, count, index)"""
+    return int(height) | (int(count) << 16) | (int(index) << 24)
+
+
+def make_params(width, height, uniforms, debug=1, mosaic=False, deferred=False, shadow_size=0, rect=None, flags=0, stripes=0):
     p = FrameParams()
     p.flags = flags
+    p.stripes = stripes
     p.width, p.height, p.shadow_size = width, height, shadow_size
     p.debugVisualisation, p.mosaicEffect, p.deferredShading = int(debug), int(bool(mosaic)), int(bool(deferred))
     if rect is not None:

@@ -108,7 +108,9 @@ __device__ __forceinline__ bool prepare_subtri(const SetupArgs& a, int32_t X0, i
 		r.bias = m * 10.0 + rr * 7.0;
 	}
 	uint32_t tx0 = (uint32_t)(px0 - (int32_t)a.view.x0) / VKR_TILE, tx1 = (uint32_t)(px1 - (int32_t)a.view.x0) / VKR_TILE;
-	uint32_t ty0 = (uint32_t)(py0 - (int32_t)a.view.y0) / VKR_TILE, ty1 = (uint32_t)(py1 - (int32_t)a.view.y0) / VKR_TILE;
+	uint32_t ly0, ly1; // the rows of this context that the bounding box reaches (a stripe partition may own none of them)
+	if (!vkr_view_local_rows(a.view, py0, py1, ly0, ly1)) return false;
+	uint32_t ty0 = ly0 / VKR_TILE, ty1 = ly1 / VKR_TILE;
 	tiles = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
 	return true;
 }

@@ -34,7 +34,7 @@ template <bool SAMECOL>
 __global__ __launch_bounds__(256) void k_deferred_light(LightArgs a)
 {
 	__shared__ float sT[257];
-	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
+	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.rows;
 	// a workgroup shades 32x8 pixels, each wavefront an 8x8 block: the pixels of a wavefront mostly lie on
 	// one surface, which is what lets whole wavefronts skip the lights behind it (below), and a workgroup's
 	// rows are whole 128-byte lines of the depth buffer (16 pixels wide, half of each line was fetched twice)
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_mosaic(const uint32_t* __restrict__ src
 	vkr_load_srgb_table(sT, thresh);
 	sDec[threadIdx.x] = decode[threadIdx.x];
 	__syncthreads();
-	const uint32_t rw = view.x1 - view.x0, rh = view.y1 - view.y0;
+	const uint32_t rw = view.x1 - view.x0, rh = view.rows;
 	// 16 x 64 pixels per workgroup, four rows per thread: the two tables are loaded once for all of them
 	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15);
 	if (x >= rw) return;
@@ -140,13 +140,13 @@ __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* dst, uint32_t value,
 
 void vkr_launch_deferred_light(hipStream_t s, const LightArgs& a)
 {
-	const uint32_t n = (a.view.x1 - a.view.x0) * (a.view.y1 - a.view.y0);
+	const uint32_t n = (a.view.x1 - a.view.x0) * a.view.rows;
 	if (!n) return;
 	// every light the same colour (the reference's braziers): the per-channel work leaves the light loop
 	bool same = true;
 	for (int i = 1; i < VKR_NUM_LIGHTS_K; i++)
 		for (int c = 0; c < 3; c++) same = same && a.lightCol[i][c] == a.lightCol[0][c];
-	const dim3 grid((a.view.x1 - a.view.x0 + 31) / 32, (a.view.y1 - a.view.y0 + 7) / 8);
+	const dim3 grid((a.view.x1 - a.view.x0 + 31) / 32, (a.view.rows + 7) / 8);
 	if (same) hipLaunchKernelGGL((k_deferred_light<true>), grid, dim3(256), 0, s, a);
 	else hipLaunchKernelGGL((k_deferred_light<false>), grid, dim3(256), 0, s, a);
 }
@@ -160,7 +160,7 @@ void vkr_launch_overvis_colour(hipStream_t s, const uint8_t* stencil, uint32_t* 
 void vkr_launch_mosaic(hipStream_t s, const uint32_t* src, uint32_t srcX0, uint32_t srcY0, uint32_t srcW, uint32_t srcH,
                        uint32_t* dst, ViewDev view, const float* srgbDecode, const float* srgbThresh)
 {
-	dim3 g((view.x1 - view.x0 + 15) / 16, (view.y1 - view.y0 + 63) / 64);
+	dim3 g((view.x1 - view.x0 + 15) / 16, (view.rows + 63) / 64);
 	hipLaunchKernelGGL(k_mosaic, g, dim3(256), 0, s, src, srcX0, srcY0, srcW, srcH, dst, view, srgbDecode, srgbThresh);
 }
 

@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 	__shared__ int sAnyAlpha;
 	const uint32_t tile = blockIdx.x;
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
-	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = (int)(a.view.y0 + ty * VKR_TILE);
-	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = min(oy + VKR_TILE, (int)a.view.y1) - 1; // inclusive
+	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = vkr_view_gy(a.view, ty * VKR_TILE);
+	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = oy + (int)min((uint32_t)VKR_TILE, a.view.rows - ty * VKR_TILE) - 1; // inclusive
 	const uint32_t tid = threadIdx.x, lane = tid & 63;
 
 	for (uint32_t i = tid; i < VKR_TILE_PIX; i += 256) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 	for (uint32_t i = tid; i < VKR_TILE_PIX; i += 256) {
 		const int px = ox + (int)(i % VKR_TILE), py = oy + (int)(i / VKR_TILE);
 		if (px > ex || py > ey) continue;
-		const size_t p = (size_t)(py - (int)a.view.y0) * rw + (size_t)(px - (int)a.view.x0);
+		const size_t p = (size_t)(ty * VKR_TILE + (uint32_t)(py - oy)) * rw + (size_t)(px - (int)a.view.x0);
 		if (MODE == RASTER_VIS) a.vis[p] = tb64[i];
 		else if (MODE == RASTER_SHADOW) a.depthOut[p] = u2f(tb32[i]);
 		else a.countOut[p] = (uint8_t)min(tb32[i], 255u); // INCREMENT_AND_CLAMP, main/main.cpp:2783
@@ -368,8 +368,8 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 	__shared__ uint32_t sListN[4], sCnt0[4];
 	__shared__ unsigned long long sKey[ALPHA_PARTS][4][64]; // per-chunk exchange of the keys of the wavefronts that share a block
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
-	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = (int)(a.view.y0 + ty * VKR_TILE);
-	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = min(oy + VKR_TILE, (int)a.view.y1) - 1;
+	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = vkr_view_gy(a.view, ty * VKR_TILE);
+	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = oy + (int)min((uint32_t)VKR_TILE, a.view.rows - ty * VKR_TILE) - 1;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	// wavefront -> (block of the quadrant, part): the ALPHA_PARTS wavefronts of a block each walk every
 	// ALPHA_PARTS-th staged entry on their own copy of the block's keys and take the minimum after each chunk;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 	const int px = ox + lx, py = oy + ly;
 	const bool inRect = px <= ex && py <= ey;
 	const uint32_t rw = a.view.x1 - a.view.x0;
-	const size_t p = (size_t)(py - (int)a.view.y0) * rw + (size_t)(px - (int)a.view.x0);
+	const size_t p = (size_t)(ty * VKR_TILE + (uint32_t)ly) * rw + (size_t)(px - (int)a.view.x0);
 	if (ox + qx > ex || oy + qy > ey) return; // quadrant outside the rectangle (whole workgroup)
 	unsigned long long key = inRect ? a.vis[p] : 0ull;
 	uint32_t wmax = wave_max_u32(inRect ? (uint32_t)(key >> 32) : 0u); // farthest depth held in the block
@@ -659,8 +659,8 @@ __global__ __launch_bounds__(1024) void k_overshade(OvershadeArgs a)
 	__shared__ unsigned long long sSort[OS_SORT_CAP];
 	const uint32_t tile = blockIdx.x;
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
-	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = (int)(a.view.y0 + ty * VKR_TILE);
-	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = min(oy + VKR_TILE, (int)a.view.y1) - 1;
+	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = vkr_view_gy(a.view, ty * VKR_TILE);
+	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = oy + (int)min((uint32_t)VKR_TILE, a.view.rows - ty * VKR_TILE) - 1;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const int bxl = (int)(wid & 3) * 8, byl = (int)(wid >> 2) * 8;
 	const int lx = bxl + (int)(lane & 7), ly = byl + (int)(lane >> 3);
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(1024) void k_overshade(OvershadeArgs a)
 	}
 	if (inRect) {
 		const uint32_t rw = a.view.x1 - a.view.x0;
-		const size_t p = (size_t)(py - (int)a.view.y0) * rw + (size_t)(px - (int)a.view.x0);
+		const size_t p = (size_t)(ty * VKR_TILE + (uint32_t)ly) * rw + (size_t)(px - (int)a.view.x0);
 		a.countOut[p] = (uint8_t)cnt;
 		if (a.depthOut) a.depthOut[p] = depth;
 	}

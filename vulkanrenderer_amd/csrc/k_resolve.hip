@@ -105,7 +105,7 @@ __device__ __forceinline__ void decode_key(unsigned long long key, float& depth,
 __global__ __launch_bounds__(256) void k_resolve_gbuf(ResolveArgs a)
 {
 	__shared__ float sDec[256];
-	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
+	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.rows;
 	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
 	const bool inside = x < rw && y < rh;
 	const size_t p = (size_t)y * rw + x;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_resolve_gbuf(ResolveArgs a)
 	sDec[threadIdx.x] = a.sc.srgbDecode[threadIdx.x];
 	__syncthreads();
 	if (!inside) return;
-	const int px = (int)(a.view.x0 + x), py = (int)(a.view.y0 + y);
+	const int px = (int)(a.view.x0 + x), py = vkr_view_gy(a.view, y);
 	float depth; uint32_t prim;
 	decode_key(key, depth, prim);
 	a.depth[p] = depth;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 {
 	__shared__ float sDec[256];
 	__shared__ float sT[257];
-	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
+	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.rows;
 	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
 	const bool inside = x < rw && y < rh;
 	const size_t p = (size_t)y * rw + x;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 	vkr_load_srgb_table(sT, a.sc.srgbThresh);
 	__syncthreads();
 	if (!inside) return;
-	const int px = (int)(a.view.x0 + x), py = (int)(a.view.y0 + y);
+	const int px = (int)(a.view.x0 + x), py = vkr_view_gy(a.view, y);
 	float depth; uint32_t prim;
 	decode_key(key, depth, prim);
 	if (a.depth) a.depth[p] = depth;
@@ -253,11 +253,11 @@ __global__ __launch_bounds__(256) void k_resolve_debug(ResolveArgs a)
 	__shared__ float sT[257];
 	vkr_load_srgb_table(sT, a.sc.srgbThresh);
 	__syncthreads();
-	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
+	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.rows;
 	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
 	if (x >= rw || y >= rh) return;
 	const size_t p = (size_t)y * rw + x;
-	const int px = (int)(a.view.x0 + x), py = (int)(a.view.y0 + y);
+	const int px = (int)(a.view.x0 + x), py = vkr_view_gy(a.view, y);
 	float depth; uint32_t prim;
 	decode_key(a.vis[p], depth, prim);
 	if (a.depth) a.depth[p] = depth;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 {
 	__shared__ float sDec[256];
 	__shared__ float sT[257];
-	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.y1 - a.view.y0;
+	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.rows;
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	const uint32_t x = blockIdx.x * 16u + (wv & 1u) * 8u + (lane & 7u), y = blockIdx.y * 16u + (wv >> 1) * 8u + (lane >> 3);
 	const bool inside = x < rw && y < rh;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	vkr_load_srgb_table(sT, l.srgbThresh);
 	__syncthreads();
 	if (!inside) return;
-	const int px = (int)(a.view.x0 + x), py = (int)(a.view.y0 + y);
+	const int px = (int)(a.view.x0 + x), py = vkr_view_gy(a.view, y);
 	float depth; uint32_t prim;
 	decode_key(key, depth, prim);
 	if (a.depth) a.depth[p] = depth;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	a.colour[p] = (depth == 1.0f) ? l.clearColour : vkr_light_pixel<SAMECOL>(l, sT, depth, gn, ga, x, y);
 }
 
-static dim3 grid16(const ViewDev& v) { return dim3((v.x1 - v.x0 + 15) / 16, (v.y1 - v.y0 + 15) / 16); }
+static dim3 grid16(const ViewDev& v) { return dim3((v.x1 - v.x0 + 15) / 16, (v.rows + 15) / 16); }
 
 void vkr_launch_resolve_gbuf(hipStream_t s, const ResolveArgs& a)
 {

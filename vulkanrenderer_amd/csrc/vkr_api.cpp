@@ -575,6 +575,7 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 }
 
 extern "C" void* vkr_context_stream(vkr_context* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int vkr_context_device(vkr_context* c) { return c ? c->device : -1; }
 
 // ---------------------------------------------------------------------------
 // profiling
@@ -963,8 +964,20 @@ static ViewDev make_view(uint32_t W, uint32_t H, uint32_t x0, uint32_t y0, uint3
 {
 	ViewDev v;
 	v.W = W; v.H = H; v.x0 = x0; v.y0 = y0; v.x1 = x1; v.y1 = y1;
+	v.rows = y1 - y0; v.stripeH = 0; v.stripeN = 1; v.stripeI = 0;
 	v.tilesX = (x1 - x0 + VKR_TILE - 1) / VKR_TILE;
 	v.tilesY = (y1 - y0 + VKR_TILE - 1) / VKR_TILE;
+	return v;
+}
+
+// sort-first by interleaved stripes: stripes index, index + count, ... of the whole frame, stored back to back
+static ViewDev make_view_stripes(uint32_t W, uint32_t H, uint32_t stripeH, uint32_t count, uint32_t index)
+{
+	ViewDev v = make_view(W, H, 0, 0, W, H);
+	uint32_t rows = 0;
+	(void)vkr_sortfirst_rows(H, count, index, stripeH, nullptr, &rows);
+	v.rows = rows; v.stripeH = stripeH; v.stripeN = count; v.stripeI = index;
+	v.tilesY = (rows + VKR_TILE - 1) / VKR_TILE;
 	return v;
 }
 
@@ -1140,7 +1153,7 @@ static int run_forward(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 	int rc;
 	if ((rc = run_shadow_beside(c, s, fp, statusSlot))) return rc;
 	vkr_context* h = shadow_owner(c);
-	const size_t n = (size_t)(view.x1 - view.x0) * (view.y1 - view.y0);
+	const size_t n = (size_t)(view.x1 - view.x0) * view.rows;
 	if ((rc = c->vis.ensure(n * 8))) return rc;
 	if ((rc = c->depth.ensure(n * 4))) return rc;
 	if ((rc = c->triId.ensure(n * 4))) return rc;
@@ -1192,8 +1205,17 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 		return set_error(VKR_E_INVALID, "rectangle [%u,%u)x[%u,%u) outside the %ux%u frame", x0, x1, y0, y1, fp.width, fp.height);
 	const uint32_t S = fp.shadow_size ? fp.shadow_size : 2048;
 	if (S > 16384) return set_error(VKR_E_INVALID, "shadow_size %u out of range", S);
-	const ViewDev view = make_view(fp.width, fp.height, x0, y0, x1, y1);
-	const size_t n = (size_t)(x1 - x0) * (y1 - y0);
+	ViewDev view = make_view(fp.width, fp.height, x0, y0, x1, y1);
+	if (fp.stripes) {
+		const uint32_t sh = fp.stripes & 0xffffu, sn = (fp.stripes >> 16) & 0xffu, si = fp.stripes >> 24;
+		if (sh == 0 || sh % VKR_TILE || sn == 0 || si >= sn)
+			return set_error(VKR_E_INVALID, "stripes: height %u (a multiple of %d), index %u of %u", sh, VKR_TILE, si, sn);
+		if (fp.rect_x0 || fp.rect_y0 || fp.rect_x1 || fp.rect_y1 || fp.mosaicEffect)
+			return set_error(VKR_E_INVALID, "stripes cannot be combined with a rectangle or with the mosaic pass");
+		if (sn > 1) view = make_view_stripes(fp.width, fp.height, sh, sn, si);
+	}
+	const size_t n = (size_t)(x1 - x0) * view.rows;
+	if (view.rows == 0) { *nPasses = 0; return VKR_OK; } // a rank whose stripes lie beyond the frame's last row
 	int rc;
 	// The presented image is written straight into the caller's buffer when that is memory of this GPU
 	// (a 33 MB device-to-device copy per 4K frame otherwise); host buffers get a copy from the context's own.

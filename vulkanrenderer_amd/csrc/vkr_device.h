@@ -105,7 +105,42 @@ struct ViewDev {
 	uint32_t W, H;           // full extent of the pass (viewport)
 	uint32_t x0, y0, x1, y1; // rectangle rendered by this context
 	uint32_t tilesX, tilesY;
+	// Rows rendered and how they map to the frame.  stripeN == 1: the rectangle's rows, local row ly = frame row y0 + ly.
+	// stripeN > 1 (sort-first by interleaved stripes; x0 = y0 = 0, x1 = W, y1 = H): of the frame cut into stripes of
+	// stripeH rows (a multiple of the tile height) this context renders stripes stripeI, stripeI + stripeN, ... and
+	// stores them back to back, so a tile row never straddles two stripes.
+	uint32_t rows;
+	uint32_t stripeH, stripeN, stripeI;
 };
+
+// frame row of local row ly
+__host__ __device__ __forceinline__ int vkr_view_gy(const ViewDev& v, uint32_t ly)
+{
+	if (v.stripeN <= 1u) return (int)(v.y0 + ly);
+	const uint32_t k = ly / v.stripeH;
+	return (int)((k * v.stripeN + v.stripeI) * v.stripeH + (ly - k * v.stripeH));
+}
+
+// local rows [ly0, ly1] (inclusive) that hold the frame rows [gy0, gy1] (inclusive, inside [y0, y1)); false if none do
+__host__ __device__ __forceinline__ bool vkr_view_local_rows(const ViewDev& v, int gy0, int gy1, uint32_t& ly0, uint32_t& ly1)
+{
+	if (gy0 > gy1) return false;
+	if (v.stripeN <= 1u) { ly0 = (uint32_t)gy0 - v.y0; ly1 = (uint32_t)gy1 - v.y0; return true; }
+	const uint32_t H = v.stripeH, N = v.stripeN, I = v.stripeI;
+	// first owned row at or below gy0 ... (rows grow downwards)
+	uint32_t s0 = (uint32_t)gy0 / H, r0 = s0 % N;
+	long long a;
+	if (r0 == I) a = (long long)(s0 / N) * H + ((uint32_t)gy0 - s0 * H);
+	else { const uint32_t s = s0 + ((I + N - r0) % N); a = (long long)(s / N) * H; if ((long long)s * H > gy1) return false; }
+	// last owned row at or above gy1
+	uint32_t s1 = (uint32_t)gy1 / H, r1 = s1 % N;
+	long long b;
+	if (r1 == I) b = (long long)(s1 / N) * H + ((uint32_t)gy1 - s1 * H);
+	else { const uint32_t back = (r1 + N - I) % N; if (back > s1) return false; const uint32_t s = s1 - back; b = (long long)(s / N) * H + (H - 1); }
+	if (a > b) return false;
+	ly0 = (uint32_t)a; ly1 = (uint32_t)b;
+	return true;
+}
 
 // ---------------------------------------------------------------------------
 // bit helpers

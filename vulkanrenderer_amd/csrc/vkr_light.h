@@ -19,7 +19,7 @@ __device__ __forceinline__ uint32_t vkr_light_pixel(const LightArgs& a, const fl
                                                     const uint32_t x, const uint32_t y)
 {
 #pragma clang fp contract(fast)
-	const float px = (float)(a.view.x0 + x), py = (float)(a.view.y0 + y);
+	const float px = (float)(a.view.x0 + x), py = (float)vkr_view_gy(a.view, y);
 	// posFromDepth: clip = (uv*2-1, depth, 1); world = (inverse(camera)*inverse(projection)) * clip
 	const float cx = ((px + 0.5f) * fast_rcp((float)a.view.W)) * 2.0f - 1.0f;
 	const float cy = ((py + 0.5f) * fast_rcp((float)a.view.H)) * 2.0f - 1.0f;

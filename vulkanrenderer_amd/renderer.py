@@ -24,7 +24,8 @@ EXPORTS = [
     "vkr_context_stream", "vkr_decode_png_file", "vkr_free", "vkr_write_png_file",
     "vkr_user_state_init", "vkr_update_user_state", "vkr_context_set_frames_in_flight",
     "vkr_wait_next_lane", "vkr_user_state_key", "vkr_user_state_button", "vkr_user_state_motion",
-    "vkr_frame_params_set_modes", "vkr_render_static",
+    "vkr_frame_params_set_modes", "vkr_render_static", "vkr_context_device", "vkr_sortfirst_rows",
+    "vkr_composite_unique_id", "vkr_compositor_create", "vkr_compositor_destroy", "vkr_composite_gather",
 ]
 
 
@@ -83,6 +84,13 @@ def lib():
         L.vkr_context_stream.restype = C.c_void_p
         L.vkr_context_stream.argtypes = [C.c_void_p]
         L.vkr_context_set_frames_in_flight.argtypes = [C.c_void_p, C.c_uint32]
+        L.vkr_context_device.argtypes = [C.c_void_p]
+        L.vkr_sortfirst_rows.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
+        L.vkr_composite_unique_id.argtypes = [C.c_char_p]
+        L.vkr_compositor_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.vkr_compositor_destroy.argtypes = [C.c_void_p]
+        L.vkr_compositor_destroy.restype = None
+        L.vkr_composite_gather.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
         L.vkr_wait_next_lane.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -174,6 +182,38 @@ def write_png(path, rgba8, flip=False):
 
 
 SIDE = ("rgba8", "tri_id", "depth_bits", "mip_level", "stencil", "gbuf_normal", "gbuf_albedo", "shadow_map")
+
+
+def sortfirst_rows(height, world, rank, stripe_height=0):
+    """(first_row, row_count) of `rank`'s share of a sort-first frame: a band (stripe_height 0) or its interleaved
+    stripes (row_count rows stored back to back, the first stripe starting at first_row)."""
+    a, b = C.c_uint32(), C.c_uint32()
+    _check(lib().vkr_sortfirst_rows(height, world, rank, stripe_height, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def composite_unique_id():
+    """The blob one rank creates and every rank passes to Compositor (an ncclUniqueId)."""
+    buf = C.create_string_buffer(128)
+    _check(lib().vkr_composite_unique_id(buf))
+    return buf.raw
+
+
+class Compositor:
+    """vkr_compositor: the RCCL exchange of sort-first rows on the context's stream."""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.h = C.c_void_p()
+        _check(lib().vkr_compositor_create(ctx.h, unique_id, rank, world, C.byref(self.h)))
+
+    def gather(self, width, height, local_ptr, frame_ptr, root=0, stripe_height=0):
+        _check(lib().vkr_composite_gather(self.h, width, height, stripe_height, local_ptr, frame_ptr, root))
+
+    def close(self):
+        if self.h:
+            lib().vkr_compositor_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 # Handles still open when the interpreter exits are released here, scenes first: a destructor that runs during
@@ -291,6 +331,8 @@ class Scene:
         if (x0, y0, x1, y1) == (0, 0, 0, 0):
             x1, y1 = W, H
         rw, rh = x1 - x0, y1 - y0
+        if params.stripes and ((params.stripes >> 16) & 0xFF) > max(1, params.stripes >> 24) and (params.stripes & 0xFFFF):
+            rh = sortfirst_rows(H, (params.stripes >> 16) & 0xFF, params.stripes >> 24, params.stripes & 0xFFFF)[1]
         S = params.shadow_size or 2048
         bufs = {
             "rgba8": np.zeros((rh, rw, 4), np.uint8), "tri_id": np.full((rh, rw), 0xFFFFFFFF, np.uint32),
