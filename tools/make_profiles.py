@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--out", default="gpurun_out")
     ap.add_argument("--fetch"); ap.add_argument("--write"); ap.add_argument("--valu"); ap.add_argument("--valu2")
     ap.add_argument("--width", type=int, default=3840); ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--workload", default="SunTemple-proxy v1 (256^2 textures), deferred, 3840x2160, fly-through pose 0")
+    ap.add_argument("--workload", default="SunTemple-proxy v1 (1024^2 textures, the benchmark's), deferred, 3840x2160, fly-through pose 0")
     a = ap.parse_args()
     if a.fetch and a.write:
         fe, wr = per_kernel(a.fetch), per_kernel(a.write)
@@ -45,7 +45,7 @@ def main():
             w = wr.get(k, {}).get("WRITE_SIZE", [])
             ks[k] = {"FETCH_SIZE_KB_avg": round(avg(f), 1), "launches_FETCH_SIZE": len(f), "WRITE_SIZE_KB_avg": round(avg(w), 1),
                      "launches_WRITE_SIZE": len(w), "hbm_bytes_per_launch_corrected": int(round((2 * avg(f) + avg(w)) * 1024))}
-        json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 tools/stage_times.py --poses 0 --reps 3 --tex-size 256",
+        json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 tools/stage_times.py --poses 0 --reps 3 --tex-size 1024",
                    "workload": a.workload, "width": a.width, "height": a.height,
                    "note": "FETCH_SIZE and WRITE_SIZE are in KB; FETCH_SIZE on gfx950 tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section), hence the doubling",
                    "kernels": ks}, open(os.path.join(a.out, a.tag + "_pmc_traffic_4k.json"), "w"), indent=1)
@@ -66,13 +66,15 @@ def main():
                  "lds_instructions_per_wave": round(avg(c1.get("SQ_INSTS_LDS", [])) / waves, 1),
                  "kernel_cycles": int(cyc),
                  "valu_busy_frac": round(avg(c1.get("SQ_ACTIVE_INST_VALU", [])) * 4.0 / (1024.0 * cyc), 3),
+                 # share of the vector ALU's issue slots used: one wave64 instruction per 2 cycles per SIMD at best
+                 "valu_issue_frac": round(avg(c1.get("SQ_INSTS_VALU", [])) * 2.0 / (1024.0 * cyc), 3),
                  "f64_instructions_per_wave": round(f64 / waves, 1)}
             if "TA_TA_BUSY_sum" in c2:
                 e["ta_busy_frac"] = round(avg(c2["TA_TA_BUSY_sum"]) / (256.0 * cyc), 3)
             ks[k] = e
-        json.dump({"command": "two passes: rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM and --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 TA_TA_BUSY_sum, each with --output-format csv -- python3 tools/stage_times.py --poses 0 --reps 2",
+        json.dump({"command": "two passes: rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM and --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 TA_TA_BUSY_sum, each with --output-format csv -- python3 tools/stage_times.py --poses 0 --reps 2 --tex-size 1024",
                    "workload": a.workload, "width": a.width, "height": a.height,
-                   "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); SQ_ACTIVE_INST_* count quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs; a value slightly above 1 means every issue slot was taken (a transcendental occupies two). ta_busy_frac = TA_TA_BUSY_sum / (256 texture-address units x kernel cycles)",
+                   "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); SQ_ACTIVE_INST_* count quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_ACTIVE_INST_VALU sums the cycles each wave spends in a vector instruction, and two waves of a SIMD overlap there, so it can exceed 1 without the ALU being saturated; valu_issue_frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles) is the share of issue slots used. ta_busy_frac = TA_TA_BUSY_sum / (256 texture-address units x kernel cycles)",
                    "kernels": ks}, open(os.path.join(a.out, a.tag + "_pmc_valu_4k.json"), "w"), indent=1)
 
 

@@ -1292,6 +1292,7 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 		} else {
 			{
 				StageTimer t(c, ST_RESOLVE_GBUF);
+				if (!out.tri_id) a.triId = nullptr; // the lighting pass reads depth and the attachments, not the ids
 				vkr_launch_resolve_gbuf(c->stream, a);
 			}
 			StageTimer t(c, ST_DEFERRED_LIGHT);

@@ -13,7 +13,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvkr_hip.so")
+# VKR_HIP_LIB: another build of the same library (kernel experiments); there is still no fallback if it is missing
+LIB_PATH = os.environ.get("VKR_HIP_LIB") or os.path.join(_HERE, "lib", "libvkr_hip.so")
 _lib = None
 
 EXPORTS = [
