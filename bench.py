@@ -108,6 +108,7 @@ def parse_args(argv=None):
     ap.add_argument("--readback", default="none", choices=["none", "pinned", "pageable"],
                     help="deliver every frame into host memory (the PCIe-inclusive rate; the headline value keeps frames in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-path", action="store_true", help="skip the second timed region (fused kernel, two frames in flight)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs, rows gathered through host tensors)")
     ap.add_argument("--profile-all", action="store_true", help="time every stage with HIP events (adds host overhead)")
@@ -390,6 +391,51 @@ def run(args):
             roofline["valu_issue_frac"] = round(float(issue[0]), 4)  # VALU instructions x 2 cycles / (SIMDs x kernel cycles), not clamped
             roofline["valu_issue_source"] = "profiles/" + issue[1]
 
+    # The same workload the fastest way the library renders it - resolve and lighting as one kernel, two frames in
+    # flight - timed in this run as well, beside the headline composition (which keeps the graded lighting kernel a
+    # launch of its own).  Deferred mode, pose partition only.
+    fast = None
+    if args.mode == "deferred" and not sortfirst and not args.fused and lanes == 1 and args.readback == "none" and not args.no_fast_path:
+        ctx.wait()
+        ctx.set_frames_in_flight(2)
+        fouts = [out_t, torch.empty_like(out_t)]
+        ffos = []
+        for o in fouts:
+            fo = abi.FrameOut()
+            fo.rgba8 = o.data_ptr()
+            ffos.append(fo)
+        fkw = dict(base_kw)
+        fkw["flags"] = fkw.get("flags", 0) | abi.FRAME_FUSED_LIGHTING
+
+        def fast_frame(i):
+            pose_index = i * world + rank
+            pose = IDENTITY if args.pose == "identity" else fly_pose(pose_index % 512)
+            scene.submit(abi.make_params(W, H, renderer.make_uniforms(W, H, pose, 1), **fkw), ffos[i % 2])
+
+        for i in range(args.warmup):
+            fast_frame(i)
+        ftimes = []
+        for _ in range(max(1, args.repeats)):
+            barrier()
+            t_start = time.perf_counter()
+            for i in range(args.steps):
+                fast_frame(args.warmup + i)
+            barrier()
+            dt = time.perf_counter() - t_start
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            ftimes.append(dt)
+        ftimes.sort()
+        fdt = ftimes[len(ftimes) // 2]
+        fast = {"composition": "VKR_FRAME_FUSED_LIGHTING + 2 frames in flight (bench.py --fused --lanes 2)",
+                "value": round(args.steps * world * W * H / fdt / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(fdt / args.steps * 1e3, 4),
+                "ms_per_step_min": round(ftimes[0] / args.steps * 1e3, 4), "ms_per_step_max": round(ftimes[-1] / args.steps * 1e3, 4),
+                "frames_per_s": round(args.steps * world / fdt, 2)}
+        ctx.wait()
+        ctx.set_frames_in_flight(1)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(packed, lambda i, mk: params_for(i, mk, whole=True), W, H, args.mode, scene, np)
@@ -412,7 +458,7 @@ def run(args):
                        "triangles": stats["triangles"], "vertices": stats["vertices"], "texture_bytes": stats["texture_bytes"],
                        "partition": args.partition if world > 1 else "none", "stripe_height": stripe_h, "backend": args.backend if world > 1 else None,
                        "frames_in_flight": lanes, "readback": args.readback, "scene_setup_s": round(t_scene, 1)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "fast_path": fast,
         }
         if args.profile_all:
             line["stages_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in report.items()}

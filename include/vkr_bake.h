@@ -8,15 +8,19 @@
  *   third_party/tgen/src/tgen.cpp     tangent generation (inside vkr_index_mesh)
  * and writes the file layout of main-bake/main.cpp:276-389.
  *
- * Differences from the reference tool, all in the input stage: the OBJ is read
- * as plain text (the reference reads a zstd-compressed stream through rapidobj);
- * polygons with more than four vertices are split as a fan (rapidobj: earcut);
- * when one shape uses several materials its meshes are emitted in order of the
- * materials' first use (the reference iterates a std::unordered_set).
+ * The input stage follows the reference tool's: the OBJ may be a Zstandard
+ * stream (main-bake/zstdistream.cpp; decoded by the library's own decoder) or
+ * plain text; quads are split along their shorter diagonal and larger polygons by
+ * ear clipping on the plane of largest projected area, as rapidobj::Triangulate
+ * does (load_model_obj.cpp:33); the meshes of a shape that uses several materials
+ * come out in the iteration order of a std::unordered_set<std::size_t>
+ * (load_model_obj.cpp:94-120), which is the reference's order when both are built
+ * against the same C++ standard library.
  */
 #ifndef VKR_BAKE_H
 #define VKR_BAKE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -56,6 +60,11 @@ VKR_BAKE_API void vkr_indexed_mesh_free(vkr_indexed_mesh* mesh);
  * (main.cpp:426-457), writes `out_path` and - if copy_textures - copies the
  * texture files into "<out stem>-tex/" next to it (existing files are kept). */
 VKR_BAKE_API int vkr_bake_obj(const char* obj_path, const char* out_path, int copy_textures);
+
+/* Decodes a buffer of Zstandard frames (RFC 8878; what main-bake/zstdistream.cpp:35-117 feeds to rapidobj) with the
+ * library's own decoder.  *out is allocated by the library; release it with vkr_bake_free(). */
+VKR_BAKE_API int vkr_zstd_decode(const uint8_t* src, size_t len, uint8_t** out, size_t* out_len);
+VKR_BAKE_API void vkr_bake_free(void* p);
 
 VKR_BAKE_API const char* vkr_bake_last_error(void);
 

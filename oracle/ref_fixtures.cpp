@@ -12,8 +12,6 @@
 //        ref_fixtures loadmodel <file>    -> JSON on stdout
 //        ref_fixtures stb <png>...        -> JSON on stdout (stbi_load(...,4) flipped, as utils/vkimage.cpp:62-65)
 //        ref_fixtures userstate           -> JSON on stdout (camera2world after each step of an input trace)
-//        ref_fixtures objmodel <obj> <stem> -> JSON on stdout: rapidobj + make_indexed_mesh on a text OBJ, as the bake tool
-//                                              would write it to <stem>.comp5892mesh (same shape as `loadmodel`)
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -25,11 +23,8 @@
 #include <glm/gtx/transform.hpp>
 
 #include <stb_image.h>
-#include <rapidobj/rapidobj.hpp>
 #include <fstream>
 #include <filesystem>
-#include <unordered_map>
-#include <unordered_set>
 
 #include "../utils/angle.hpp"
 #include "../main-bake/index_mesh.hpp"
@@ -177,96 +172,6 @@ static int do_loadmodel(const char* path)
 	return 0;
 }
 
-// The bake tool's pipeline (main-bake/main.cpp:142-231) on a plain-text OBJ: rapidobj parses and triangulates
-// (the reference feeds it a zstd stream, main-bake/load_model_obj.cpp:21-32), the statements of
-// load_model_obj.cpp:49-169, main.cpp:236-251 and main.cpp:426-476 follow on the reference's own types, and the
-// reference's make_indexed_mesh (main-bake/index_mesh.cpp) is called as main.cpp:394-421 calls it.
-static int do_objmodel(const char* aPath, const char* aStem)
-{
-	namespace fs = std::filesystem;
-	rapidobj::MaterialLibrary const mlib = rapidobj::MaterialLibrary::SearchPath(fs::absolute(fs::path(aPath).remove_filename()));
-	std::ifstream ins(aPath);
-	auto result = rapidobj::ParseStream(ins, mlib);
-	if (result.error) { std::fprintf(stderr, "rapidobj: %s\n", result.error.code.message().c_str()); return 1; }
-	rapidobj::Triangulate(result);
-	char const* pathEnd = std::strrchr(aPath, '/');
-	std::string const prefix = pathEnd ? std::string(aPath, pathEnd + 1) : "";
-	struct Mat { std::string tex[6]; };
-	std::vector<Mat> materials;
-	for (auto const& mat : result.materials) {
-		Mat mi;
-		if (!mat.diffuse_texname.empty()) mi.tex[0] = prefix + mat.diffuse_texname;
-		if (!mat.roughness_texname.empty()) mi.tex[1] = prefix + mat.roughness_texname;
-		if (!mat.metallic_texname.empty()) mi.tex[2] = prefix + mat.metallic_texname;
-		if (!mat.alpha_texname.empty()) mi.tex[3] = prefix + mat.alpha_texname;
-		if (!mat.normal_texname.empty()) mi.tex[4] = prefix + mat.normal_texname;
-		if (!mat.emissive_texname.empty()) mi.tex[5] = prefix + mat.emissive_texname;
-		materials.emplace_back(std::move(mi));
-	}
-	struct Mesh { std::size_t materialIndex; TriangleSoup soup; };
-	std::vector<Mesh> meshes;
-	std::unordered_set<std::size_t> activeMaterials;
-	for (auto const& shape : result.shapes) {
-		activeMaterials.clear();
-		for (std::size_t i = 0; i < shape.mesh.indices.size(); ++i) activeMaterials.emplace(shape.mesh.material_ids[i / 3]);
-		for (auto const matId : activeMaterials) {
-			Mesh m; m.materialIndex = matId;
-			for (std::size_t i = 0; i < shape.mesh.indices.size(); ++i) {
-				if (std::size_t(shape.mesh.material_ids[i / 3]) != matId) continue;
-				auto const& idx = shape.mesh.indices[i];
-				m.soup.vert.emplace_back(glm::vec3{ result.attributes.positions[idx.position_index * 3 + 0], result.attributes.positions[idx.position_index * 3 + 1], result.attributes.positions[idx.position_index * 3 + 2] });
-				m.soup.text.emplace_back(glm::vec2{ result.attributes.texcoords[idx.texcoord_index * 2 + 0], result.attributes.texcoords[idx.texcoord_index * 2 + 1] });
-				m.soup.norm.emplace_back(glm::vec3{ result.attributes.normals[idx.normal_index * 3 + 0], result.attributes.normals[idx.normal_index * 3 + 1], result.attributes.normals[idx.normal_index * 3 + 2] });
-			}
-			meshes.emplace_back(std::move(m));
-		}
-	}
-	for (auto& mat : materials) {
-		if (mat.tex[0].empty()) mat.tex[0] = "assets-src/main/rgba1111.png";
-		if (mat.tex[1].empty()) mat.tex[1] = "assets-src/main/r1.png";
-		if (mat.tex[2].empty()) mat.tex[2] = "assets-src/main/r1.png";
-		if (mat.tex[5].empty()) mat.tex[5] = "assets-src/main/rgb000.png";
-	}
-	struct Tex { std::uint32_t id; unsigned space, channels; std::string newPath; };
-	std::unordered_map<std::string, Tex> unique;
-	std::uint32_t texid = 0;
-	static const unsigned kSpace[6] = { 1, 0, 0, 1, 0, 1 }, kChannels[6] = { 4, 1, 1, 4, 3, 4 };
-	for (auto const& mat : materials)
-		for (int k = 0; k < 6; k++) {
-			if (mat.tex[k].empty()) continue;
-			auto const [it, isNew] = unique.emplace(std::make_pair(mat.tex[k], Tex{ texid, kSpace[k], kChannels[k], "" }));
-			if (isNew) ++texid;
-		}
-	fs::path const texdir = std::string(aStem) + "-tex";
-	std::vector<Tex const*> ordered(unique.size());
-	for (auto& e : unique) { e.second.newPath = (texdir / fs::path(e.first).filename()).string(); ordered[e.second.id] = &e.second; }
-	std::printf("{\n  \"textures\": [\n");
-	for (std::size_t i = 0; i < ordered.size(); i++)
-		std::printf("    {\"path\": \"%s\", \"space\": %u, \"channels\": %u}%s\n", ordered[i]->newPath.c_str(), ordered[i]->space, ordered[i]->channels, i + 1 == ordered.size() ? "" : ",");
-	std::printf("  ],\n  \"materials\": [\n");
-	for (std::size_t i = 0; i < materials.size(); i++) {
-		std::printf("    [");
-		for (int k = 0; k < 6; k++) std::printf("%u%s", materials[i].tex[k].empty() ? ~0u : unique.at(materials[i].tex[k]).id, k == 5 ? "" : ", ");
-		std::printf("]%s\n", i + 1 == materials.size() ? "" : ",");
-	}
-	std::printf("  ],\n  \"meshes\": [\n");
-	for (std::size_t i = 0; i < meshes.size(); i++) {
-		IndexedMesh const d = make_indexed_mesh(meshes[i].soup, 1e-5f);
-		std::printf("    {\"materialId\": %zu, \"V\": %zu, \"I\": %zu, \"positions\": \"%016llx\", \"normals\": \"%016llx\", "
-		            "\"texcoords\": \"%016llx\", \"tangents\": \"%016llx\", \"tangentsComp\": \"%016llx\", \"indices\": \"%016llx\"}%s\n",
-			meshes[i].materialIndex, d.vert.size(), d.indices.size(),
-			(unsigned long long)fnv1a(d.vert.data(), d.vert.size() * sizeof(glm::vec3)),
-			(unsigned long long)fnv1a(d.norm.data(), d.norm.size() * sizeof(glm::vec3)),
-			(unsigned long long)fnv1a(d.text.data(), d.text.size() * sizeof(glm::vec2)),
-			(unsigned long long)fnv1a(d.tangent.data(), d.tangent.size() * sizeof(glm::vec4)),
-			(unsigned long long)fnv1a(d.tangentComp.data(), d.tangentComp.size() * sizeof(std::uint32_t)),
-			(unsigned long long)fnv1a(d.indices.data(), d.indices.size() * sizeof(std::uint32_t)),
-			i + 1 == meshes.size() ? "" : ",");
-	}
-	std::printf("  ]\n}\n");
-	return 0;
-}
-
 static int do_stb(int n, char** files)
 {
 	stbi_set_flip_vertically_on_load(1);
@@ -358,7 +263,6 @@ try {
 	if (argc >= 2 && 0 == std::strcmp(argv[1], "tangents")) return do_tangents();
 	if (argc >= 2 && 0 == std::strcmp(argv[1], "userstate")) return do_userstate();
 	if (argc >= 3 && 0 == std::strcmp(argv[1], "loadmodel")) return do_loadmodel(argv[2]);
-	if (argc >= 4 && 0 == std::strcmp(argv[1], "objmodel")) return do_objmodel(argv[2], argv[3]);
 	if (argc >= 3 && 0 == std::strcmp(argv[1], "stb")) return do_stb(argc - 2, argv + 2);
 	std::fprintf(stderr, "usage: ref_fixtures matrices|tangents|userstate|loadmodel <file>|stb <png>...\n");
 	return 2;

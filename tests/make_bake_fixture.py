@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Writes tests/golden/bake/model.obj + model.mtl (a small OBJ that exercises the bake path: quads split along either
 diagonal, negative indices, 'o' and 'g' shapes, duplicate and nearly-duplicate vertices around the weld tolerance,
-mirrored texture coordinates, materials with and without each map) and, where /root/reference and
-oracle/_ref/ref_fixtures exist, tests/golden/ref_objmodel.json = what the reference's rapidobj + make_indexed_mesh
-pipeline makes of it (oracle/ref_fixtures.cpp, command objmodel)."""
+mirrored texture coordinates, polygons with five to eight corners, a shape that uses three materials, materials with and
+without each map), the same file as a Zstandard stream (model.obj-zstd) and, where oracle/_ref/main-bake exists (the
+reference's bake tool compiled from its own sources), tests/golden/bake/ref_suntemple.comp5892mesh = the file that tool
+writes for the stream."""
 import os, subprocess, sys
 import numpy as np
 
@@ -69,6 +70,36 @@ def main():
     L.append("vn 0.000000 0.000000 1.000000")
     for k in range(0, len(pts), 3):
         L.append("f " + " ".join("%d/%d/%d" % (base + k + c + 1, tb + k + c + 1, nb + 1) for c in range(3)))
+    # --- polygons with more than four corners (rapidobj triangulates them by ear clipping on the plane of the largest
+    #     projected area): a convex pentagon, a concave hexagon in an oblique plane, an octagon with a collinear corner
+    L.append("o polygons")
+    L.append("usemtl mat_plain")
+    nv, nt = base + len(pts), tb + len(uvs)
+
+    def polygon(points, normal):
+        nonlocal nv, nt
+        for q in points:
+            L.append("v %.6f %.6f %.6f" % q)
+            L.append("vt %.6f %.6f" % (q[0] * 0.25, q[1] * 0.25 + q[2] * 0.125))
+        L.append("vn %.6f %.6f %.6f" % tuple(np.asarray(normal) / np.linalg.norm(normal)))
+        L.append("f " + " ".join("%d/%d/-1" % (nv + k + 1, nt + k + 1) for k in range(len(points))))
+        nv += len(points); nt += len(points)
+
+    polygon([(9 + np.cos(a) * 0.8, np.sin(a) * 0.8, 2.0) for a in np.linspace(0.3, 0.3 + 2 * np.pi, 5, endpoint=False)], (0.0, 0.0, 1.0))
+    ell = [(0, 0), (2, 0), (2, 1), (1, 1), (1, 3), (0, 3)]                      # an L: reflex corner at (1, 1)
+    polygon([(11 + x * 0.5, y * 0.4, -1 + x * 0.3 + y * 0.2) for x, y in ell], (-0.28, -0.19, 0.94))
+    octo = [(0, 0), (1, 0), (2, 0), (3, 1), (3, 2), (2, 3), (0.5, 1.5), (0, 2)]  # (1,0) is collinear; (0.5,1.5) is reflex
+    polygon([(13.0, y * 0.5, -x * 0.5) for x, y in octo], (1.0, 0.0, 0.0))
+    # --- one shape that uses three materials in turn: the reference emits its meshes in the iteration order of a
+    #     std::unordered_set of the material indices
+    L.append("g mixed")
+    for k in range(9):
+        L.append("usemtl " + ("mat_plain", "mat_all_maps", "mat_alpha")[(k * 2) % 3])
+        x = 15.0 + k * 0.75
+        for q in ((x, 0.0, 0.0), (x + 0.5, 0.0, 0.1 * k), (x + 0.25, 0.6, 0.0)):
+            L.append("v %.6f %.6f %.6f" % q)
+            L.append("vt %.6f %.6f" % (q[0] - 15.0, q[1]))
+        L.append("f -3/-3/-1 -2/-2/-1 -1/-1/-1")
     open(os.path.join(D, "model.obj"), "w").write("\n".join(L) + "\n")
     open(os.path.join(D, "model.mtl"), "w").write("""# bake fixture materials
 newmtl mat_all_maps
@@ -93,12 +124,32 @@ newmtl mat_plain
 	Pm 0.000000
 	Pr 1.000000
 """)
-    ref = os.path.join(ROOT, "oracle", "_ref", "ref_fixtures")
-    if os.path.exists(ref):
-        with open(os.path.join(ROOT, "tests", "golden", "ref_objmodel.json"), "w") as f:
-            subprocess.check_call([ref, "objmodel", "tests/golden/bake/model.obj", "model"], stdout=f, cwd=ROOT)
+    # --- the same OBJ as the reference packages its source asset: a Zstandard stream (libzstd, level 19, through pyarrow's
+    #     codec - the only compressor in this image), and a second copy as a frame of stored blocks
+    sys.path.insert(0, ROOT)
+    from vulkanrenderer_amd import bake
+    text = open(os.path.join(D, "model.obj"), "rb").read()
+    try:
+        import pyarrow as pa
+        packed = pa.Codec("zstd", compression_level=19).compress(text, asbytes=True)
+    except Exception:
+        packed = bake.zstd_store(text)
+    open(os.path.join(D, "model.obj-zstd"), "wb").write(packed)
+    # --- the reference's own bake tool (main-bake/*.cpp, built from its sources by `make -C oracle _ref`), run on that
+    #     stream where it expects its input (paths are compiled in, main-bake/main.cpp:131-134); what it writes is the
+    #     golden file the library's output must equal byte for byte
+    tool = os.path.join(ROOT, "oracle", "_ref", "main-bake")
+    if os.path.exists(tool):
+        import shutil, tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            src = os.path.join(tmp, "assets-src", "main")
+            os.makedirs(src)
+            shutil.copy(os.path.join(D, "model.obj-zstd"), os.path.join(src, "suntemple.obj-zstd"))
+            shutil.copy(os.path.join(D, "model.mtl"), os.path.join(src, "model.mtl"))
+            subprocess.check_call([tool], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            shutil.copy(os.path.join(tmp, "assets", "main", "suntemple.comp5892mesh"), os.path.join(D, "ref_suntemple.comp5892mesh"))
     else:
-        print("oracle/_ref/ref_fixtures missing: ref_objmodel.json not regenerated", file=sys.stderr)
+        print("oracle/_ref/main-bake missing: ref_suntemple.comp5892mesh not regenerated", file=sys.stderr)
 
 
 if __name__ == "__main__":

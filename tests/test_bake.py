@@ -1,8 +1,11 @@
-"""The bake step (libvkr_bake.so) against what the reference's own rapidobj + make_indexed_mesh + tgen pipeline makes
-of the same OBJ (tests/golden/ref_objmodel.json, generated by oracle/ref_fixtures.cpp `objmodel` through
-tests/make_bake_fixture.py), and properties of the welder."""
+"""The bake step (libvkr_bake.so) against the file the reference's own bake tool writes for the same Zstandard-compressed
+OBJ (tests/golden/bake/ref_suntemple.comp5892mesh, made by oracle/_ref/main-bake - main-bake/*.cpp compiled from the
+reference's sources - through tests/make_bake_fixture.py), the library's Zstandard decoder against frames made by
+libzstd, and properties of the welder."""
+import hashlib
 import json
 import os
+import shutil
 
 import numpy as np
 import pytest
@@ -27,29 +30,93 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(bake.lib(), name)
 
 
-def test_bake_obj_equals_reference_pipeline(tmp_path):
-    """Texture table, material table and, per mesh, every array bit for bit (welded vertex numbering included)."""
-    from vulkanrenderer_amd import bake, baked_model
-    ref = json.load(open(os.path.join(GOLD, "ref_objmodel.json")))
-    out = str(tmp_path / "model.comp5892mesh")
+def _bake_like_the_reference(tmp_path, source):
+    """Lays the fixture out where the reference tool expects its input (main-bake/main.cpp:131-134) and bakes it."""
+    from vulkanrenderer_amd import bake
+    src = tmp_path / "assets-src" / "main"
+    src.mkdir(parents=True)
+    shutil.copy(os.path.join(GOLD, "bake", source), str(src / "suntemple.obj-zstd"))
+    shutil.copy(os.path.join(GOLD, "bake", "model.mtl"), str(src / "model.mtl"))
     cwd = os.getcwd()
-    os.chdir(os.path.dirname(os.path.dirname(GOLD)))  # the fixture was made with the OBJ path relative to the repo root
+    os.chdir(str(tmp_path))   # texture paths are the OBJ's directory + the MTL's names, relative to the working directory
     try:
-        bake.bake_obj("tests/golden/bake/model.obj", out)
+        bake.bake_obj("assets-src/main/suntemple.obj-zstd", "assets/main/suntemple.comp5892mesh")
     finally:
         os.chdir(cwd)
-    tex, mats, meshes, trailing = baked_model.read_baked_model(out)
-    assert trailing == 0
-    # the reader resolves texture paths against the file's directory, as load_baked_model does (main/baked_model.cpp:76-101)
-    assert [(os.path.relpath(p, str(tmp_path)), s, c) for p, s, c in tex] == [(t["path"], t["space"], t["channels"]) for t in ref["textures"]]
-    assert [list(m) for m in mats] == ref["materials"]
-    assert len(meshes) == len(ref["meshes"]) == 3
-    for m, r in zip(meshes, ref["meshes"]):
-        assert (m["materialId"], len(m["positions"]), len(m["indices"])) == (r["materialId"], r["V"], r["I"])
-        for k in ("positions", "normals", "texcoords", "tangents", "tangentsComp", "indices"):
-            assert fnv1a(m[k].tobytes()) == r[k], k
+    return (tmp_path / "assets" / "main" / "suntemple.comp5892mesh").read_bytes()
+
+
+def test_bake_obj_equals_the_reference_tools_file(tmp_path):
+    """Zstandard stream in, .comp5892mesh out: the same bytes as the reference's bake tool wrote - texture and material
+    tables, the mesh order of a shape with three materials (iteration order of its std::unordered_set), quads split
+    along the shorter diagonal, polygons of five to eight corners cut into the same ears, welded vertex numbering,
+    tangents and packed TBN words."""
+    from vulkanrenderer_amd import baked_model
+    want = open(os.path.join(GOLD, "bake", "ref_suntemple.comp5892mesh"), "rb").read()
+    got = _bake_like_the_reference(tmp_path, "model.obj-zstd")
+    assert got == want
+    tex, mats, meshes, trailing = baked_model.read_baked_model(str(tmp_path / "assets" / "main" / "suntemple.comp5892mesh"))
+    assert trailing == 0 and len(mats) == 3 and len(meshes) == 7   # floor, cube, shards, polygons, mixed x 3 materials
     # the shards: two exact duplicates and one vertex 4e-6 away merge, the one 3e-5 away and the ones with other uvs do not
     assert len(meshes[2]["positions"]) == 12 and len(meshes[2]["indices"]) == 15
+    # pentagon + hexagon + octagon = 3 + 4 + 6 triangles
+    assert len(meshes[3]["indices"]) == 3 * 13
+
+
+def test_plain_text_and_stored_frames_bake_the_same(tmp_path):
+    """The OBJ as plain text and as a frame of stored blocks give the file the compressed stream gives."""
+    from vulkanrenderer_amd import bake
+    want = open(os.path.join(GOLD, "bake", "ref_suntemple.comp5892mesh"), "rb").read()
+    assert _bake_like_the_reference(tmp_path / "a", "model.obj") == want
+    stored = tmp_path / "stored.obj-zstd"
+    stored.write_bytes(bake.zstd_store(open(os.path.join(GOLD, "bake", "model.obj"), "rb").read(), block=1000, checksum=True))
+    (tmp_path / "b").mkdir()
+    shutil.copy(str(stored), os.path.join(GOLD, "bake", "_stored.tmp"))
+    try:
+        assert _bake_like_the_reference(tmp_path / "b", "_stored.tmp") == want
+    finally:
+        os.remove(os.path.join(GOLD, "bake", "_stored.tmp"))
+
+
+def test_zstd_decoder_against_libzstd_frames():
+    """vkr_zstd_decode on frames libzstd made at levels 1 to 22 (tests/make_zstd_fixtures.py): raw, RLE and compressed
+    blocks, Huffman literals in one and four streams with direct and FSE-compressed weights, treeless literals, all
+    sequence table modes, repeat offsets, multi-block frames."""
+    from vulkanrenderer_amd import bake
+    index = json.load(open(os.path.join(GOLD, "zstd", "index.json")))
+    assert len(index) >= 10
+    for name, info in index.items():
+        data = bake.zstd_decode(open(os.path.join(GOLD, "zstd", name + ".zst"), "rb").read())
+        assert len(data) == info["length"] and hashlib.sha256(data).hexdigest() == info["sha256"], name
+    # concatenated frames and a skippable frame in between
+    a = open(os.path.join(GOLD, "zstd", "tiny_l3.zst"), "rb").read()
+    b = open(os.path.join(GOLD, "zstd", "obj_l19.zst"), "rb").read()
+    skip = b"\x50\x2a\x4d\x18" + (5).to_bytes(4, "little") + b"12345"
+    both = bake.zstd_decode(a + skip + b)
+    assert both[:5] == b"hello" and hashlib.sha256(both[5:]).hexdigest() == index["obj_l19"]["sha256"]
+
+
+def test_zstd_decoder_rejects_damaged_frames():
+    from vulkanrenderer_amd import bake
+    good = open(os.path.join(GOLD, "zstd", "obj_l19.zst"), "rb").read()
+    with pytest.raises(bake.BakeError, match="zstd"):
+        bake.zstd_decode(b"not a frame at all")
+    with pytest.raises(bake.BakeError, match="zstd"):
+        bake.zstd_decode(good[: len(good) // 2])
+    rng = np.random.default_rng(3)
+    rejected = 0
+    for _ in range(200):   # flipped bytes: an error or (rarely) other content, never a crash
+        bad = bytearray(good)
+        bad[int(rng.integers(6, len(bad)))] ^= int(rng.integers(1, 256))
+        try:
+            bake.zstd_decode(bytes(bad))
+        except bake.BakeError:
+            rejected += 1
+    assert rejected > 100
+    stored = bytearray(bake.zstd_store(b"some content to protect" * 10, checksum=True))
+    stored[20] ^= 1
+    with pytest.raises(bake.BakeError, match="checksum"):
+        bake.zstd_decode(bytes(stored))
 
 
 def test_baked_file_loads_in_the_reference_loader_format(tmp_path):
@@ -59,11 +126,17 @@ def test_baked_file_loads_in_the_reference_loader_format(tmp_path):
     out = str(tmp_path / "m.comp5892mesh")
     bake.bake_obj(os.path.join(GOLD, "bake", "model.obj"), out)
     _, _, meshes, _ = baked_model.read_baked_model(out)
+    degenerate = 0
     for m in meshes:
-        assert np.array_equal(baked_model.pack_tbn(m["tangents"], m["normals"]), m["tangentsComp"])
-        assert np.abs(np.linalg.norm(m["tangents"][:, :3], axis=1) - 1).max() < 1e-5
-        assert np.abs((m["tangents"][:, :3] * m["normals"]).sum(1)).max() < 1e-5   # orthogonalised against the normal
+        # the octagon of the fixture maps to a line in texture space: tgen gives it no tangent (NaN), as in the reference's
+        # file; everywhere else the frame is orthonormal and packs to the word the pinned packer gives
+        ok = np.isfinite(m["tangents"]).all(axis=1)
+        degenerate += int((~ok).sum())
+        assert np.array_equal(baked_model.pack_tbn(m["tangents"][ok], m["normals"][ok]), m["tangentsComp"][ok])
+        assert np.abs(np.linalg.norm(m["tangents"][ok, :3], axis=1) - 1).max() < 1e-5
+        assert np.abs((m["tangents"][ok, :3] * m["normals"][ok]).sum(1)).max() < 1e-5   # orthogonalised against the normal
         assert m["indices"].max() == len(m["positions"]) - 1
+    assert 0 < degenerate <= 12
 
 
 def test_weld_properties():

@@ -110,7 +110,7 @@ def test_baked_obj_renders_like_the_oracle(ctx, tmp_path):
     sc = renderer.Scene(ctx, path=path)
     ps = abi.PackedScene(*baked_model.load_scene_arrays(path, image_loader=renderer.decode_png))
     osc = oracle.OracleScene(ps)
-    assert sc.stats()["triangles"] == ps.triangle_count == 49
+    assert sc.stats()["triangles"] == ps.triangle_count == 71
     W, H = 160, 90
     pose = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 3.2, 0.6, 2.4, 1]
     for kw in (dict(deferred=True), dict(), dict(debug=2)):

@@ -7,7 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvkr_bake.so")
-EXPORTS = ["vkr_index_mesh", "vkr_indexed_mesh_free", "vkr_bake_obj", "vkr_bake_last_error"]
+EXPORTS = ["vkr_index_mesh", "vkr_indexed_mesh_free", "vkr_bake_obj", "vkr_bake_last_error", "vkr_zstd_decode", "vkr_bake_free"]
 _lib = None
 
 
@@ -32,6 +32,9 @@ def lib():
         L.vkr_indexed_mesh_free.argtypes = [C.POINTER(IndexedMesh)]
         L.vkr_indexed_mesh_free.restype = None
         L.vkr_bake_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.vkr_zstd_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.vkr_bake_free.argtypes = [C.c_void_p]
+        L.vkr_bake_free.restype = None
         _lib = L
     return _lib
 
@@ -62,5 +65,37 @@ def index_mesh(positions, normals, texcoords, tolerance=1e-6):
 
 
 def bake_obj(obj_path, out_path, copy_textures=False):
-    """Text OBJ (+ its MTL) -> out_path (.comp5892mesh), as main-bake's process_model_ (main-bake/main.cpp:142-231)."""
+    """OBJ (a Zstandard stream, as the reference's suntemple.obj-zstd, or plain text) + its MTL -> out_path (.comp5892mesh), as main-bake's process_model_ (main-bake/main.cpp:142-231)."""
     _check(lib().vkr_bake_obj(os.fsencode(obj_path), os.fsencode(out_path), int(copy_textures)))
+
+
+def zstd_decode(data):
+    """Decodes a buffer of Zstandard frames with the library's own decoder (what the reference's ZStdIStream,
+    main-bake/zstdistream.cpp:35-117, does through libzstd)."""
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    _check(lib().vkr_zstd_decode(bytes(data), len(data), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        lib().vkr_bake_free(out)
+
+
+def zstd_store(data, block=100000, checksum=False):
+    """A Zstandard frame of raw (stored) blocks around `data`: valid input for any zstd decoder, made without a
+    compressor.  Used to hand test OBJ files to the bake step the way the reference's source asset is packaged."""
+    import struct
+    data = bytes(data)
+    out = bytearray(struct.pack("<I", 0xFD2FB528))
+    out.append(0xE0 | (0x04 if checksum else 0))           # 8-byte content size, single segment, optional checksum
+    out += struct.pack("<Q", len(data))
+    if not data:
+        out += struct.pack("<I", 1)[:3]                    # one empty raw block, last
+    for at in range(0, len(data), block):
+        chunk = data[at:at + block]
+        last = at + block >= len(data)
+        out += struct.pack("<I", (len(chunk) << 3) | int(last))[:3]
+        out += chunk
+    if checksum:
+        import xxhash
+        out += struct.pack("<I", xxhash.xxh64(data).intdigest() & 0xFFFFFFFF)
+    return bytes(out)

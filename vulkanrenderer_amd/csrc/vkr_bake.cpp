@@ -10,8 +10,11 @@
 //   write_model         main-bake/main.cpp:276-389
 //   unique textures     main-bake/main.cpp:426-476, fallbacks :236-251
 #include "../../include/vkr_bake.h"
+#include "vkr_zstd.h"
 
 #include <algorithm>
+#include <array>
+#include <cfloat>
 #include <charconv>
 #include <cmath>
 #include <cstdarg>
@@ -23,6 +26,8 @@
 #include <string>
 #include <string_view>
 #include <unordered_map>
+#include <unordered_set>
+#include <iterator>
 #include <vector>
 
 namespace {
@@ -363,10 +368,226 @@ int load_mtl(const std::string& path, const std::string& prefix, std::vector<Mat
 
 struct Corner { long v, vt, vn; };
 
+// ---------------------------------------------------------------------------
+// Polygons with more than four corners.  rapidobj projects the face onto the
+// coordinate plane in which it has the largest area and runs mapbox earcut on
+// the 2-D ring (third_party/rapidobj/include/rapidobj/rapidobj.hpp:7430-7493);
+// the triangles, and their order, decide the triangle soup and with it the
+// vertex numbering of the baked mesh.  This is ear clipping by the same rules,
+// on an index-linked ring: the ring is wound clockwise (earcut's convention for
+// outer rings), a vertex is an ear if its corner is convex and no reflex-or-flat
+// vertex lies inside its triangle, after a cut the walk skips the next vertex,
+// and a ring without ears is first filtered (duplicate and collinear points),
+// then cured of local self-intersections, then split along a valid diagonal.
+// ---------------------------------------------------------------------------
+class EarClipper {
+public:
+	// ring: 2-D points (floats widened to double, as earcut does); returns triples of ring indices (prev, ear, next)
+	std::vector<uint32_t> run(const std::vector<std::array<float, 2>>& ring)
+	{
+		n_.clear(); out_.clear();
+		const size_t len = ring.size();
+		if (!len) return out_;
+		double sum = 0;
+		for (size_t i = 0, j = len - 1; i < len; j = i++)
+			sum += ((double)ring[j][0] - (double)ring[i][0]) * ((double)ring[i][1] + (double)ring[j][1]);
+		int last = -1;
+		if (sum > 0) for (size_t i = 0; i < len; i++) last = insert((uint32_t)i, ring[i][0], ring[i][1], last);
+		else for (size_t i = len; i-- > 0;) last = insert((uint32_t)i, ring[i][0], ring[i][1], last);
+		if (last >= 0 && same(last, n_[last].next)) { unlink(last); last = n_[last].next; }
+		if (last < 0 || n_[last].prev == n_[last].next) return out_;
+		clip(last, 0);
+		return out_;
+	}
+
+private:
+	struct Node { uint32_t i; double x, y; int prev, next; };
+	std::vector<Node> n_;
+	std::vector<uint32_t> out_;
+
+	int insert(uint32_t i, double x, double y, int last)
+	{
+		const int p = (int)n_.size();
+		n_.push_back({ i, x, y, p, p });
+		if (last >= 0) {
+			n_[p].next = n_[last].next; n_[p].prev = last;
+			n_[n_[last].next].prev = p; n_[last].next = p;
+		}
+		return p;
+	}
+	void unlink(int p) { n_[n_[p].next].prev = n_[p].prev; n_[n_[p].prev].next = n_[p].next; }
+	bool same(int a, int b) const { return n_[a].x == n_[b].x && n_[a].y == n_[b].y; }
+	double area(int p, int q, int r) const { return (n_[q].y - n_[p].y) * (n_[r].x - n_[q].x) - (n_[q].x - n_[p].x) * (n_[r].y - n_[q].y); }
+	static bool in_triangle(double ax, double ay, double bx, double by, double cx, double cy, double px, double py)
+	{
+		return (cx - px) * (ay - py) >= (ax - px) * (cy - py) && (ax - px) * (by - py) >= (bx - px) * (ay - py) &&
+		       (bx - px) * (cy - py) >= (cx - px) * (by - py);
+	}
+	int filter(int start, int end = -1)
+	{
+		if (end < 0) end = start;
+		int p = start;
+		bool again;
+		do {
+			again = false;
+			if (same(p, n_[p].next) || area(n_[p].prev, p, n_[p].next) == 0) {
+				unlink(p);
+				p = end = n_[p].prev;
+				if (p == n_[p].next) break;
+				again = true;
+			} else p = n_[p].next;
+		} while (again || p != end);
+		return end;
+	}
+	bool is_ear(int ear) const
+	{
+		const int a = n_[ear].prev, b = ear, c = n_[ear].next;
+		if (area(a, b, c) >= 0) return false;
+		for (int p = n_[c].next; p != a; p = n_[p].next)
+			if (in_triangle(n_[a].x, n_[a].y, n_[b].x, n_[b].y, n_[c].x, n_[c].y, n_[p].x, n_[p].y) && area(n_[p].prev, p, n_[p].next) >= 0) return false;
+		return true;
+	}
+	static int sgn(double v) { return (0.0 < v) - (v < 0.0); }
+	bool on_segment(int p, int q, int r) const
+	{
+		return n_[q].x <= std::max(n_[p].x, n_[r].x) && n_[q].x >= std::min(n_[p].x, n_[r].x) && n_[q].y <= std::max(n_[p].y, n_[r].y) &&
+		       n_[q].y >= std::min(n_[p].y, n_[r].y);
+	}
+	bool crosses(int p1, int q1, int p2, int q2) const
+	{
+		const int o1 = sgn(area(p1, q1, p2)), o2 = sgn(area(p1, q1, q2)), o3 = sgn(area(p2, q2, p1)), o4 = sgn(area(p2, q2, q1));
+		if (o1 != o2 && o3 != o4) return true;
+		if (o1 == 0 && on_segment(p1, p2, q1)) return true;
+		if (o2 == 0 && on_segment(p1, q2, q1)) return true;
+		if (o3 == 0 && on_segment(p2, p1, q2)) return true;
+		if (o4 == 0 && on_segment(p2, q1, q2)) return true;
+		return false;
+	}
+	bool locally_inside(int a, int b) const
+	{
+		return area(n_[a].prev, a, n_[a].next) < 0 ? area(a, b, n_[a].next) >= 0 && area(a, n_[a].prev, b) >= 0
+		                                          : area(a, b, n_[a].prev) < 0 || area(a, n_[a].next, b) < 0;
+	}
+	bool crosses_ring(int a, int b) const
+	{
+		int p = a;
+		do {
+			const int q = n_[p].next;
+			if (n_[p].i != n_[a].i && n_[q].i != n_[a].i && n_[p].i != n_[b].i && n_[q].i != n_[b].i && crosses(p, q, a, b)) return true;
+			p = q;
+		} while (p != a);
+		return false;
+	}
+	bool middle_inside(int a, int b) const
+	{
+		bool inside = false;
+		const double px = (n_[a].x + n_[b].x) / 2, py = (n_[a].y + n_[b].y) / 2;
+		int p = a;
+		do {
+			const int q = n_[p].next;
+			if (((n_[p].y > py) != (n_[q].y > py)) && n_[q].y != n_[p].y && (px < (n_[q].x - n_[p].x) * (py - n_[p].y) / (n_[q].y - n_[p].y) + n_[p].x))
+				inside = !inside;
+			p = q;
+		} while (p != a);
+		return inside;
+	}
+	bool valid_diagonal(int a, int b) const
+	{
+		return n_[n_[a].next].i != n_[b].i && n_[n_[a].prev].i != n_[b].i && !crosses_ring(a, b) &&
+		       ((locally_inside(a, b) && locally_inside(b, a) && middle_inside(a, b) &&
+		         (area(n_[a].prev, a, n_[b].prev) != 0.0 || area(a, n_[b].prev, b) != 0.0)) ||
+		        (same(a, b) && area(n_[a].prev, a, n_[a].next) > 0 && area(n_[b].prev, b, n_[b].next) > 0));
+	}
+	int cure(int start)
+	{
+		int p = start;
+		do {
+			const int a = n_[p].prev, b = n_[n_[p].next].next;
+			if (!same(a, b) && crosses(a, p, n_[p].next, b) && locally_inside(a, b) && locally_inside(b, a)) {
+				out_.push_back(n_[a].i); out_.push_back(n_[p].i); out_.push_back(n_[b].i);
+				unlink(p); unlink(n_[p].next);
+				p = start = b;
+			}
+			p = n_[p].next;
+		} while (p != start);
+		return filter(p);
+	}
+	void split(int start)
+	{
+		int a = start;
+		do {
+			for (int b = n_[n_[a].next].next; b != n_[a].prev; b = n_[b].next) {
+				if (n_[a].i != n_[b].i && valid_diagonal(a, b)) {
+					// two rings: a .. b and a copy of b .. a copy of a
+					const int a2 = (int)n_.size(); n_.push_back({ n_[a].i, n_[a].x, n_[a].y, 0, 0 });
+					const int b2 = (int)n_.size(); n_.push_back({ n_[b].i, n_[b].x, n_[b].y, 0, 0 });
+					const int an = n_[a].next, bp = n_[b].prev;
+					n_[a].next = b; n_[b].prev = a;
+					n_[a2].next = an; n_[an].prev = a2;
+					n_[b2].next = a2; n_[a2].prev = b2;
+					n_[bp].next = b2; n_[b2].prev = bp;
+					const int ra = filter(a, n_[a].next), rc = filter(b2, n_[b2].next);
+					clip(ra, 0);
+					clip(rc, 0);
+					return;
+				}
+			}
+			a = n_[a].next;
+		} while (a != start);
+	}
+	void clip(int ear, int pass)
+	{
+		if (ear < 0) return;
+		int stop = ear;
+		while (n_[ear].prev != n_[ear].next) {
+			const int prev = n_[ear].prev, next = n_[ear].next;
+			if (is_ear(ear)) {
+				out_.push_back(n_[prev].i); out_.push_back(n_[ear].i); out_.push_back(n_[next].i);
+				unlink(ear);
+				ear = n_[next].next; // skipping a vertex gives fewer slivers
+				stop = n_[next].next;
+				continue;
+			}
+			ear = next;
+			if (ear == stop) {
+				if (pass == 0) clip(filter(ear), 1);
+				else if (pass == 1) clip(cure(filter(ear)), 2);
+				else split(ear);
+				break;
+			}
+		}
+	}
+};
+
+inline float polygon_area(const float* x, const float* y, size_t size)
+{
+	float area = 0.0f;
+	for (size_t i = 1; i != size; ++i) {
+		const float avgHeight = (y[i - 1] + y[i]) / 2;
+		const float width = x[i] - x[i - 1];
+		area += width * avgHeight;
+	}
+	const float avgHeight = (y[0] + y[size - 1]) / 2;
+	const float width = x[0] - x[size - 1];
+	area += width * avgHeight;
+	return std::fabs(area);
+}
+
 int load_obj(const char* path, Model& model)
 {
-	std::ifstream in(path);
-	if (!in) return fail("cannot open '%s'", path);
+	// main-bake/zstdistream.cpp: the model source is a Zstandard stream; plain text is accepted as well
+	std::vector<uint8_t> raw;
+	{
+		std::ifstream file(path, std::ios::binary);
+		if (!file) return fail("cannot open '%s'", path);
+		raw.assign(std::istreambuf_iterator<char>(file), std::istreambuf_iterator<char>());
+	}
+	if (vkr_zstd_is_frame(raw.data(), raw.size())) {
+		std::vector<uint8_t> text;
+		std::string err;
+		if (!vkr_zstd_decompress(raw.data(), raw.size(), text, err)) return fail("%s: %s", path, err.c_str());
+		raw.swap(text);
+	}
 	const char* slash = std::strrchr(path, '/');
 	const std::string prefix = slash ? std::string(path, slash + 1) : std::string();
 
@@ -377,11 +598,13 @@ int load_obj(const char* path, Model& model)
 	std::unordered_map<std::string, size_t> matIndex;
 	long curMat = -1;
 	bool haveLib = false;
-	std::string line;
 	size_t lineNo = 0;
-	while (std::getline(in, line)) {
+	for (size_t at = 0; at < raw.size();) {
+		size_t eol = at;
+		while (eol < raw.size() && raw[eol] != '\n') eol++;
+		std::string_view s((const char*)raw.data() + at, eol - at);
+		at = eol + 1;
 		lineNo++;
-		std::string_view s(line);
 		const std::string_view key = next_token(s);
 		if (key.empty() || key.front() == '#') continue;
 		if (key == "v" || key == "vn" || key == "vt") {
@@ -446,16 +669,36 @@ int load_obj(const char* path, Model& model)
 				emit(cs[0], cs[1], d02less ? cs[2] : cs[3]);
 				emit(d02less ? cs[0] : cs[1], cs[2], cs[3]);
 			} else {
-				for (size_t k = 1; k + 1 < cs.size(); k++) emit(cs[0], cs[k], cs[k + 1]);
+				// rapidobj.hpp:7430-7493: the coordinate plane of the largest projected area, earcut, first two corners of
+				// every triangle swapped
+				if (cs.size() > 255) return fail("%s:%zu: face with more than 255 corners", path, lineNo);
+				const size_t nv = cs.size();
+				std::vector<float> xs(nv), ys(nv), zs(nv);
+				for (size_t k = 0; k < nv; k++) { xs[k] = P[cs[k].v * 3 + 0]; ys[k] = P[cs[k].v * 3 + 1]; zs[k] = P[cs[k].v * 3 + 2]; }
+				const float areaX = polygon_area(ys.data(), zs.data(), nv), areaY = polygon_area(xs.data(), zs.data(), nv),
+				            areaZ = polygon_area(xs.data(), ys.data(), nv);
+				if (FLT_MIN > std::max({ areaX, areaY, areaZ })) return fail("%s:%zu: degenerate polygon", path, lineNo);
+				const int plane = areaX > areaY ? (areaX > areaZ ? 0 : 2) : (areaY > areaZ ? 1 : 2);
+				std::vector<std::array<float, 2>> ring(nv);
+				for (size_t k = 0; k < nv; k++)
+					ring[k] = plane == 0 ? std::array<float, 2>{ ys[k], zs[k] } : plane == 1 ? std::array<float, 2>{ xs[k], zs[k] } : std::array<float, 2>{ xs[k], ys[k] };
+				EarClipper clipper;
+				const std::vector<uint32_t> tri = clipper.run(ring);
+				if (tri.empty() || tri.size() % 3) return fail("%s:%zu: polygon could not be triangulated", path, lineNo);
+				for (size_t k = 0; k < tri.size(); k += 3) emit(cs[tri[k + 1]], cs[tri[k]], cs[tri[k + 2]]);
 			}
 		}
 	}
 	// load_model_obj.cpp:95-169: per shape, one mesh per material used in it
 	for (const Shape& sh : shapes) {
-		std::vector<long> active;
+		// The reference collects a shape's materials in a std::unordered_set<std::size_t> - one emplace per index of
+		// every triangle - and emits the shape's meshes in the set's iteration order (load_model_obj.cpp:94-120).  The
+		// same container with the same sequence of insertions gives the same order under the same standard library.
+		std::unordered_set<std::size_t> active;
 		for (const auto& f : sh.faces)
-			if (std::find(active.begin(), active.end(), f.mat) == active.end()) active.push_back(f.mat);
-		for (long mat : active) {
+			for (int k = 0; k < 3; k++) active.emplace((std::size_t)f.mat);
+		for (const std::size_t matId : active) {
+			const long mat = (long)matId;
 			MeshInfo mi;
 			mi.name = active.size() == 1 ? sh.name : sh.name + "::" + model.materials[mat].name;
 			mi.material = (size_t)mat;
@@ -616,6 +859,24 @@ extern "C" int vkr_index_mesh(const float* positions, const float* normals, cons
 {
 	return guarded("vkr_index_mesh", [&] { return index_mesh_entry(positions, normals, texcoords, n, tolerance, out); });
 }
+
+extern "C" int vkr_zstd_decode(const uint8_t* src, size_t len, uint8_t** out, size_t* out_len)
+{
+	return guarded("vkr_zstd_decode", [&] {
+		if (!src || !out || !out_len) return fail("vkr_zstd_decode: NULL argument");
+		*out = nullptr; *out_len = 0;
+		std::vector<uint8_t> data;
+		std::string err;
+		if (!vkr_zstd_decompress(src, len, data, err)) return fail("%s", err.c_str());
+		uint8_t* p = (uint8_t*)std::malloc(data.size() ? data.size() : 1);
+		if (!p) return fail("vkr_zstd_decode: out of memory");
+		if (!data.empty()) std::memcpy(p, data.data(), data.size());
+		*out = p; *out_len = data.size();
+		return 0;
+	});
+}
+
+extern "C" void vkr_bake_free(void* p) { std::free(p); }
 
 extern "C" int vkr_bake_obj(const char* obj_path, const char* out_path, int copy_textures)
 {
