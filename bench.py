@@ -262,8 +262,11 @@ def run(args):
     W, H = args.width, args.height
     t0 = time.time()
     packed = scenes.proxy_scene(detail=args.detail, tex_size=args.tex_size)
+    t_generate = time.time() - t0  # synthesis of the proxy scene in numpy: no part of the library
     ctx = renderer.Context(local_rank)
-    scene = renderer.Scene(ctx, packed)
+    t1 = time.time()
+    scene = renderer.Scene(ctx, packed)  # vkr_scene_create: upload, mip chains, repacked chains, tables
+    t_create = time.time() - t1
     stats = scene.stats()
     t_scene = time.time() - t0
 
@@ -457,7 +460,8 @@ def run(args):
                        "mode": args.mode, "width": W, "height": H,
                        "triangles": stats["triangles"], "vertices": stats["vertices"], "texture_bytes": stats["texture_bytes"],
                        "partition": args.partition if world > 1 else "none", "stripe_height": stripe_h, "backend": args.backend if world > 1 else None,
-                       "frames_in_flight": lanes, "readback": args.readback, "scene_setup_s": round(t_scene, 1)},
+                       "frames_in_flight": lanes, "readback": args.readback, "scene_setup_s": round(t_scene, 2),
+                       "scene_generate_s": round(t_generate, 2), "scene_create_s": round(t_create, 2)},
             "roofline": roofline, "cpu_baseline": cpu, "fast_path": fast,
         }
         if args.profile_all:

@@ -19,10 +19,14 @@ __device__ __forceinline__ void decode_texel(uint32_t p, int srgb, const float* 
 	out[3] = (float)(p >> 24) / 255.0f;
 }
 
-__global__ __launch_bounds__(256) void k_mip_level(uint32_t* texels, uint32_t srcOff, uint32_t sw, uint32_t sh, uint32_t dstOff,
-                                                    uint32_t dw, uint32_t dh, int srgb, const float* __restrict__ decode,
+// One launch builds the same level of many textures: blockIdx.z picks the job.  The grid covers the largest
+// destination of the batch; blocks beyond a smaller one leave at once.
+__global__ __launch_bounds__(256) void k_mip_level(uint32_t* texels, const MipJob* __restrict__ jobs, const float* __restrict__ decode,
                                                     const float* __restrict__ thresh)
 {
+	const MipJob jb = jobs[blockIdx.z];
+	const uint32_t sw = jb.sw, sh = jb.sh, dw = jb.dw, dh = jb.dh;
+	const int srgb = jb.srgb;
 	const uint32_t i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
 	if (i >= dw || j >= dh) return;
 	const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
@@ -33,7 +37,7 @@ __global__ __launch_bounds__(256) void k_mip_level(uint32_t* texels, uint32_t sr
 	int y0 = (int)y0f, y1 = y0 + 1, x0 = (int)x0f, x1 = x0 + 1;
 	y0 = min(max(y0, 0), (int)sh - 1); y1 = min(max(y1, 0), (int)sh - 1);
 	x0 = min(max(x0, 0), (int)sw - 1); x1 = min(max(x1, 0), (int)sw - 1);
-	const uint32_t* src = texels + srcOff;
+	const uint32_t* src = texels + jb.srcOff;
 	float t00[4], t10[4], t01[4], t11[4];
 	decode_texel(src[(size_t)y0 * sw + x0], srgb, decode, t00);
 	decode_texel(src[(size_t)y0 * sw + x1], srgb, decode, t10);
@@ -48,14 +52,17 @@ __global__ __launch_bounds__(256) void k_mip_level(uint32_t* texels, uint32_t sr
 		uint32_t code = (srgb && c < 3) ? vkr_srgb_encode(thresh, v) : vkr_unorm_encode(v);
 		out |= code << (8 * c);
 	}
-	texels[dstOff + (size_t)j * dw + i] = out;
+	texels[jb.dstOff + (size_t)j * dw + i] = out;
 }
 
-void vkr_launch_mip_level(hipStream_t s, uint32_t* texels, uint32_t srcOff, uint32_t sw, uint32_t sh, uint32_t dstOff,
-                          uint32_t dw, uint32_t dh, int srgb, const float* srgbDecode, const float* srgbThresh)
+void vkr_launch_mip_levels(hipStream_t s, uint32_t* texels, const MipJob* jobs, uint32_t count, uint32_t maxW, uint32_t maxH,
+                           const float* srgbDecode, const float* srgbThresh)
 {
-	dim3 g((dw + 15) / 16, (dh + 15) / 16);
-	hipLaunchKernelGGL(k_mip_level, g, dim3(256), 0, s, texels, srcOff, sw, sh, dstOff, dw, dh, srgb, srgbDecode, srgbThresh);
+	// grid.z is limited to 65535 blocks
+	for (uint32_t first = 0; first < count; first += 65535u) {
+		const uint32_t n = count - first < 65535u ? count - first : 65535u;
+		hipLaunchKernelGGL(k_mip_level, dim3((maxW + 15) / 16, (maxH + 15) / 16, n), dim3(256), 0, s, texels, jobs + first, srgbDecode, srgbThresh);
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -84,33 +91,47 @@ void vkr_launch_tbn_table(hipStream_t s, const uint32_t* tcomp, float4* out, uin
 // Alpha bytes of one texture's whole mip chain (levels are stored back to
 // back), for the alpha test of the rasteriser.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_extract_alpha(const uint32_t* __restrict__ texels, uint8_t* __restrict__ out, uint32_t n)
+// Both kernels below walk a list of spans (blockIdx.y picks the span, blockIdx.x strides over its texels), so that one
+// launch serves every texture of the scene.
+__global__ __launch_bounds__(256) void k_extract_alpha(const uint32_t* __restrict__ texels, uint8_t* __restrict__ out,
+                                                        const SpanJob* __restrict__ jobs)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) out[i] = (uint8_t)(texels[i] >> 24);
+	const SpanJob jb = jobs[blockIdx.y];
+	const uint32_t* src = texels + jb.a;
+	uint8_t* dst = out + jb.out;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) dst[i] = (uint8_t)(src[i] >> 24);
 }
 
-void vkr_launch_extract_alpha(hipStream_t s, const uint32_t* texels, uint8_t* out, uint32_t n)
+static uint32_t span_blocks(uint32_t maxN) { return (maxN + 255) / 256 < 4096u ? (maxN + 255) / 256 : 4096u; }
+
+void vkr_launch_extract_alpha(hipStream_t s, const uint32_t* texels, uint8_t* out, const SpanJob* jobs, uint32_t count, uint32_t maxN)
 {
-	if (!n) return;
-	hipLaunchKernelGGL(k_extract_alpha, dim3((n + 255) / 256), dim3(256), 0, s, texels, out, n);
+	if (!maxN) return;
+	for (uint32_t first = 0; first < count; first += 65535u) // grid.y is limited to 65535 blocks
+		hipLaunchKernelGGL(k_extract_alpha, dim3(span_blocks(maxN), count - first < 65535u ? count - first : 65535u), dim3(256), 0, s,
+		                   texels, out, jobs + first);
 }
 
 // ---------------------------------------------------------------------------
 // Repacked chain: the colour bytes of one chain and the first byte of another
 // (same size, levels stored back to back) in one texel.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_chain(const uint32_t* __restrict__ rgb, const uint32_t* __restrict__ a,
-                                                     uint32_t* __restrict__ out, uint32_t n)
+__global__ __launch_bounds__(256) void k_pack_chain(uint32_t* texels, const SpanJob* __restrict__ jobs)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) out[i] = (rgb[i] & 0x00ffffffu) | (a[i] << 24);
+	const SpanJob jb = jobs[blockIdx.y];
+	const uint32_t* rgb = texels + jb.rgb;
+	const uint32_t* a = texels + jb.a;
+	uint32_t* out = texels + jb.out;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x)
+		out[i] = (rgb[i] & 0x00ffffffu) | (a[i] << 24);
 }
 
-void vkr_launch_pack_chain(hipStream_t s, const uint32_t* rgb, const uint32_t* a, uint32_t* out, uint32_t n)
+void vkr_launch_pack_chains(hipStream_t s, uint32_t* texels, const SpanJob* jobs, uint32_t count, uint32_t maxN)
 {
-	if (!n) return;
-	hipLaunchKernelGGL(k_pack_chain, dim3((n + 255) / 256), dim3(256), 0, s, rgb, a, out, n);
+	if (!maxN) return;
+	for (uint32_t first = 0; first < count; first += 65535u)
+		hipLaunchKernelGGL(k_pack_chain, dim3(span_blocks(maxN), count - first < 65535u ? count - first : 65535u), dim3(256), 0, s,
+		                   texels, jobs + first);
 }
 
 // ---------------------------------------------------------------------------

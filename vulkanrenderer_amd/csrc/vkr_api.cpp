@@ -860,13 +860,41 @@ static int scene_create_impl(vkr_context* c, const vkr_scene_desc* d, vkr_scene*
 		hipError_t e = hipMemcpyAsync(s->texels.as<uint32_t>() + s->htex[i].off[0], t.rgba8, (size_t)t.width * t.height * 4,
 		                              hipMemcpyHostToDevice, c->stream);
 		if (e != hipSuccess) return fail(set_error(VKR_E_DEVICE, "texture upload: %s", hipGetErrorString(e)));
-		for (int l = 1; l < s->htex[i].levels; l++)
-			vkr_launch_mip_level(c->stream, s->texels.as<uint32_t>(), s->htex[i].off[l - 1], s->htex[i].w[l - 1], s->htex[i].h[l - 1],
-			                     s->htex[i].off[l], s->htex[i].w[l], s->htex[i].h[l], s->htex[i].srgb, c->dDecode, c->dThresh);
 	}
-	for (const Pack& p : packs)
-		vkr_launch_pack_chain(c->stream, s->texels.as<uint32_t>() + s->htex[p.rgb].off[0], s->texels.as<uint32_t>() + s->htex[p.a].off[0],
-		                      s->texels.as<uint32_t>() + s->htex[p.id].off[0], chain_texels(p.id));
+	// Levels 1.. of every chain and the repacked chains, batched: level l of all textures is one launch (it reads
+	// level l-1, finished by the launch before it on the stream), all repacked chains are one more.
+	struct Ingest { DevBuf mip, span; ~Ingest() { mip.release(); span.release(); } } ingest;
+	{
+		int maxLevels = 0;
+		for (uint32_t i = 0; i < d->textureCount; i++) maxLevels = s->htex[i].levels > maxLevels ? s->htex[i].levels : maxLevels;
+		std::vector<MipJob> jobs;
+		struct Batch { uint32_t first, count, maxW, maxH; };
+		std::vector<Batch> batches;
+		for (int l = 1; l < maxLevels; l++) {
+			Batch b{ (uint32_t)jobs.size(), 0, 0, 0 };
+			for (uint32_t i = 0; i < d->textureCount; i++) {
+				const HostTex& h = s->htex[i];
+				if (l >= h.levels) continue;
+				jobs.push_back({ h.off[l - 1], h.off[l], (uint16_t)h.w[l - 1], (uint16_t)h.h[l - 1], (uint16_t)h.w[l], (uint16_t)h.h[l], h.srgb });
+				b.maxW = h.w[l] > b.maxW ? h.w[l] : b.maxW;
+				b.maxH = h.h[l] > b.maxH ? h.h[l] : b.maxH;
+				b.count++;
+			}
+			if (b.count) batches.push_back(b);
+		}
+		if (!jobs.empty()) {
+			if ((rc = upload(ingest.mip, jobs.data(), jobs.size() * sizeof(MipJob)))) return fail(rc);
+			for (const Batch& b : batches)
+				vkr_launch_mip_levels(c->stream, s->texels.as<uint32_t>(), ingest.mip.as<MipJob>() + b.first, b.count, b.maxW, b.maxH, c->dDecode, c->dThresh);
+		}
+	}
+	std::vector<SpanJob> spans;
+	uint32_t packMax = 0;
+	for (const Pack& p : packs) {
+		spans.push_back({ s->htex[p.rgb].off[0], s->htex[p.a].off[0], s->htex[p.id].off[0], chain_texels(p.id) });
+		packMax = spans.back().n > packMax ? spans.back().n : packMax;
+	}
+	const size_t nPackSpans = spans.size();
 
 	// ---- materials: binding table + whether the alpha test can ever discard
 	std::vector<int> lowAlpha(d->textureCount, -1);
@@ -906,10 +934,17 @@ static int scene_create_impl(vkr_context* c, const vkr_scene_desc* d, vkr_scene*
 			bytes += chain_texels(minfo[i].tex[3]);
 		}
 		if ((rc = s->alphaTexels.ensure(bytes ? bytes : 4))) return fail(rc);
+		uint32_t alphaMax = 0;
 		for (uint32_t t = 0; t < d->textureCount; t++) {
 			if (tinfo[t].alphaOff == 0xffffffffu) continue;
-			const HostTex& h = s->htex[t];
-			vkr_launch_extract_alpha(c->stream, s->texels.as<uint32_t>() + h.off[0], s->alphaTexels.as<uint8_t>() + tinfo[t].alphaOff, chain_texels(t));
+			spans.push_back({ 0u, s->htex[t].off[0], tinfo[t].alphaOff, chain_texels(t) });
+			alphaMax = spans.back().n > alphaMax ? spans.back().n : alphaMax;
+		}
+		if (!spans.empty()) {
+			if ((rc = upload(ingest.span, spans.data(), spans.size() * sizeof(SpanJob)))) return fail(rc);
+			vkr_launch_pack_chains(c->stream, s->texels.as<uint32_t>(), ingest.span.as<SpanJob>(), (uint32_t)nPackSpans, packMax);
+			vkr_launch_extract_alpha(c->stream, s->texels.as<uint32_t>(), s->alphaTexels.as<uint8_t>(), ingest.span.as<SpanJob>() + nPackSpans,
+			                         (uint32_t)(spans.size() - nPackSpans), alphaMax);
 		}
 	}
 	if ((rc = upload(s->tex, tinfo.data(), tinfo.size() * sizeof(TexInfo)))) return fail(rc);

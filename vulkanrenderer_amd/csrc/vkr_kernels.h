@@ -125,11 +125,14 @@ void vkr_launch_resolve_light(hipStream_t s, const ResolveArgs& a, const LightAr
 void vkr_launch_overvis_colour(hipStream_t s, const uint8_t* stencil, uint32_t* colour, const float* srgbThresh, uint32_t n);
 void vkr_launch_mosaic(hipStream_t s, const uint32_t* src, uint32_t srcX0, uint32_t srcY0, uint32_t srcW, uint32_t srcH,
                        uint32_t* dst, ViewDev view, const float* srgbDecode, const float* srgbThresh);
-void vkr_launch_mip_level(hipStream_t s, uint32_t* texels, uint32_t srcOff, uint32_t sw, uint32_t sh, uint32_t dstOff,
-                          uint32_t dw, uint32_t dh, int srgb, const float* srgbDecode, const float* srgbThresh);
-void vkr_launch_extract_alpha(hipStream_t s, const uint32_t* texels, uint8_t* out, uint32_t n);
+// scene ingest, batched: one launch per mip level over every texture that has it, one launch for all spans
+struct MipJob { uint32_t srcOff, dstOff; uint16_t sw, sh, dw, dh; int32_t srgb; };
+struct SpanJob { uint32_t rgb, a, out, n; }; // texel offsets of the sources (`rgb` unused by extract_alpha), destination offset, count
+void vkr_launch_mip_levels(hipStream_t s, uint32_t* texels, const MipJob* jobs, uint32_t count, uint32_t maxW, uint32_t maxH,
+                           const float* srgbDecode, const float* srgbThresh);
+void vkr_launch_extract_alpha(hipStream_t s, const uint32_t* texels, uint8_t* out, const SpanJob* jobs, uint32_t count, uint32_t maxN);
 void vkr_launch_alpha_aux(hipStream_t s, const SceneDev& sc, AlphaAux* out);
 void vkr_launch_tri_shade(hipStream_t s, const SceneDev& sc, TriShade* out);
-void vkr_launch_pack_chain(hipStream_t s, const uint32_t* rgb, const uint32_t* a, uint32_t* out, uint32_t n);
+void vkr_launch_pack_chains(hipStream_t s, uint32_t* texels, const SpanJob* jobs, uint32_t count, uint32_t maxN);
 void vkr_launch_tbn_table(hipStream_t s, const uint32_t* tcomp, float4* out, uint32_t nVert);
 void vkr_launch_fill_u32(hipStream_t s, uint32_t* dst, uint32_t value, size_t n);

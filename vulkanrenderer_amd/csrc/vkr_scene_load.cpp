@@ -8,8 +8,11 @@
 // = 255, 16-bit samples reduced to their high byte, rows bottom-up.
 #include "../../include/vkr_renderer.h"
 
+#include <sched.h>
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +20,8 @@
 #include <exception>
 #include <new>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 int vkr_set_error_ext(int code, const char* fmt, ...); // vkr_api.cpp
@@ -279,11 +284,41 @@ static int scene_load_impl(vkr_context* ctx, const char* path, vkr_scene** out)
 	}
 	if (rd.off != rd.n) fprintf(stderr, "Note: '%s' contains trailing bytes\n", path); // main/baked_model.cpp:170-171
 
-	for (auto& t : tex) {
-		std::vector<uint8_t> png;
-		if (!read_file(t.path, png)) return vkr_set_error_ext(VKR_E_IO, "%s: Unable to load texture base image (cannot open)", t.path.c_str());
-		std::string err = decode_png(png, t.rgba, t.w, t.h);
-		if (!err.empty()) return vkr_set_error_ext(VKR_E_IO, "%s: Unable to load texture base image (%s)", t.path.c_str(), err.c_str());
+	// Every image is read and decoded on its own; a small pool of host threads takes them in file order.  The error
+	// reported is that of the first texture in file order that failed, as a sequential loop would report it.
+	{
+		std::vector<std::string> errs(nTex);
+		std::atomic<uint32_t> next{ 0 };
+		std::atomic<bool> failed{ false };
+		auto work = [&]() {
+			for (uint32_t i; !failed.load(std::memory_order_relaxed) && (i = next.fetch_add(1)) < nTex;) {
+				Tex& t = tex[i];
+				try {
+					std::vector<uint8_t> png;
+					if (!read_file(t.path, png)) errs[i] = "cannot open";
+					else errs[i] = decode_png(png, t.rgba, t.w, t.h);
+				} catch (const std::exception& e) {
+					errs[i] = e.what();
+				}
+				if (!errs[i].empty()) failed.store(true, std::memory_order_relaxed);
+			}
+		};
+		cpu_set_t cpus;
+		unsigned avail = sched_getaffinity(0, sizeof cpus, &cpus) == 0 ? (unsigned)CPU_COUNT(&cpus) : 1u;
+		const unsigned nThreads = std::max(1u, std::min({ avail, 16u, (unsigned)nTex }));
+		std::vector<std::thread> pool;
+		try {
+			for (unsigned k = 1; k < nThreads; k++) pool.emplace_back(work);
+		} catch (const std::system_error&) {
+			// no more threads to be had: the ones running and this one do the work
+		}
+		work();
+		for (auto& th : pool) th.join();
+		// a worker stops taking images once one has failed, so images after the failure may be missing: that is fine,
+		// the load fails; the ones before it were all taken (indices are handed out in order) and have finished
+		for (uint32_t i = 0; i < nTex; i++)
+			if (!errs[i].empty())
+				return vkr_set_error_ext(VKR_E_IO, "%s: Unable to load texture base image (%s)", tex[i].path.c_str(), errs[i].c_str());
 	}
 	// the arrays inside the file buffer may be unaligned: copy them out
 	std::vector<std::vector<uint8_t>> keep;

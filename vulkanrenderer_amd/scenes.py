@@ -7,6 +7,9 @@ camera, its forward light (main/main.cpp:1314) and all 21 brazier lights
 assets-src/main/suntemple.mtl) and four textures per material.  A small
 "micro" scene with the same features is used by the parity tests.
 """
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 from .abi import NO_TEXTURE, PackedScene
@@ -112,13 +115,17 @@ def sphere_bowl(center, radius, nseg, nring, material):
 # --------------------------------------------------------------------------
 # procedural textures
 # --------------------------------------------------------------------------
-def _value_noise(rng, size, octaves=5, base=4):
-    """Tileable value noise in [0,1], size x size."""
+def _noise_grids(rng, size, octaves=5, base=4):
+    """The random lattices of one value-noise image (everything that consumes the generator)."""
+    return [rng.random((min(base << o, size),) * 2, dtype=np.float32) for o in range(octaves)]
+
+
+def _value_noise(grids, size):
+    """Tileable value noise in [0,1], size x size, from the lattices of _noise_grids."""
     out = np.zeros((size, size), np.float32)
     amp, tot = 1.0, 0.0
-    for o in range(octaves):
-        n = min(base << o, size)
-        g = rng.random((n, n), dtype=np.float32)
+    for g in grids:
+        n = g.shape[0]
         rep = size // n
         # bilinear upsample with wrap
         gx = np.concatenate([g, g[:, :1]], axis=1)
@@ -133,14 +140,19 @@ def _value_noise(rng, size, octaves=5, base=4):
     return out / tot
 
 
-def material_textures(rng, size, tint, alpha_mask=False):
+def material_draw(rng, size):
+    """The random numbers of one material's textures: the only part that must run in sequence."""
+    return _noise_grids(rng, size), _noise_grids(rng, size, octaves=3)
+
+
+def material_textures(draw, size, tint, alpha_mask=False):
     """Four (five with the mask) RGBA8 level-0 images for one material, laid out
     as stb returns them for the asset kinds of the real scene: RGB(A) base
     colour, grey roughness / metalness replicated to RGB with alpha 255, RGB
-    tangent-space normal map."""
-    n0 = _value_noise(rng, size)
+    tangent-space normal map.  `draw` comes from material_draw."""
+    n0 = _value_noise(draw[0], size)
     n1 = np.roll(n0, (size // 3, size // 5), axis=(0, 1))
-    n2 = _value_noise(rng, size, octaves=3)
+    n2 = _value_noise(draw[1], size)
     base = np.empty((size, size, 4), np.uint8)
     shade = 0.35 + 0.65 * n0
     for c in range(3):
@@ -174,9 +186,9 @@ def material_textures(rng, size, tint, alpha_mask=False):
     return tex
 
 
-def _add_material(rng, textures, materials, size, tint, alpha_mask=False):
+def _add_material(rng, textures, materials, size, tint, alpha_mask=False, built=None):
     t0 = len(textures)
-    textures.extend(material_textures(rng, size, tint, alpha_mask))
+    textures.extend(built if built is not None else material_textures(material_draw(rng, size), size, tint, alpha_mask))
     # BakedMaterialInfo order: baseColor, roughness, metalness, alphaMask, normalMap, emissive
     materials.append((t0, t0 + 1, t0 + 2, (t0 + 4) if alpha_mask else NO_TEXTURE, t0 + 3, t0))
     return len(materials) - 1
@@ -249,8 +261,17 @@ def proxy_scene(detail=1.0, tex_size=1024, seed=PROXY_SEED, materials_total=48, 
     textures, materials = [], []
     tints = rng.random((materials_total, 3)) * 0.6 + 0.35
     alpha_ids = {15, 37, 40}  # three alpha-masked materials, as suntemple.mtl:131,330,349
+    # the lattices are drawn in sequence (they fix the scene's bytes); the images are then built on a thread pool
+    draws = [material_draw(rng, tex_size) for _ in range(materials_total)]
+    workers = max(1, min(16, len(os.sched_getaffinity(0)), materials_total)) if tex_size >= 256 else 1
+    build = lambda i: material_textures(draws[i], tex_size, tints[i], i in alpha_ids)
+    if workers > 1:
+        with ThreadPoolExecutor(workers) as pool:
+            built = list(pool.map(build, range(materials_total)))
+    else:
+        built = [build(i) for i in range(materials_total)]
     for i in range(materials_total):
-        _add_material(rng, textures, materials, tex_size, tints[i], alpha_mask=(i in alpha_ids))
+        _add_material(rng, textures, materials, tex_size, tints[i], alpha_mask=(i in alpha_ids), built=built[i])
     opaque = [i for i in range(materials_total) if i not in alpha_ids]
     alpha = sorted(alpha_ids)
     meshes = []
