@@ -115,9 +115,25 @@ __device__ __forceinline__ void bcast_subtri(const SubTri& s, int bx0, int by0, 
 // Every sub-triangle of the tile's bin that needs no alpha test.  In
 // RASTER_VIS mode alpha-tested sub-triangles are left to k_raster_alpha and
 // such tiles are flagged in alphaTiles.
+#ifdef VKR_WG_TIMES
+// measurement build only: per-workgroup phase clocks (100 MHz) and bin sizes of the last k_raster launch of each mode
+__device__ unsigned long long g_wgTimes[3][8 * 32768];
+extern "C" __attribute__((visibility("default"))) int vkr_debug_wg_times(int mode, void* dst, size_t bytes)
+{
+	return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wgTimes), bytes, (size_t)mode * sizeof(g_wgTimes[0]), hipMemcpyDeviceToHost);
+}
+#define WG_T(k) if (threadIdx.x == 0) wgT[k] = wall_clock64()
+#else
+#define WG_T(k)
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 {
+#ifdef VKR_WG_TIMES
+	unsigned long long wgT[6];
+	WG_T(0);
+#endif
 	__shared__ unsigned long long tb64[MODE == RASTER_VIS ? VKR_TILE_PIX : 1];
 	__shared__ uint32_t tb32[MODE == RASTER_VIS ? 1 : VKR_TILE_PIX];
 	__shared__ int sAnyAlpha;
@@ -134,6 +150,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 	}
 	if (tid == 0) sAnyAlpha = 0;
 	__syncthreads();
+	WG_T(1);
 
 	uint32_t beg = a.tileOffset[tile], end = a.tileOffset[tile + 1];
 	if (end > a.binCap) end = a.binCap;
@@ -149,6 +166,8 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 	// lane nine lanes in ten would idle.  The lanes of a group take every group-th column of the bounding box.
 	const uint32_t logG = n <= 64u ? 2u : n <= 128u ? 1u : 0u, G = 1u << logG;
 	const uint32_t sub = lane & (G - 1u);
+	if (n == 0xffffffffu) return; // never: makes the header loads complete before the clock is read
+	WG_T(2);
 	for (uint32_t base = 0; base < n; base += 256u >> logG) {
 		// entries are dealt to the four wavefronts round-robin, so a short bin still spreads its
 		// large (wave-cooperative) sub-triangles over all of them
@@ -212,7 +231,9 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 			}
 		}
 	}
+	WG_T(3);
 	__syncthreads();
+	WG_T(4);
 
 	const uint32_t rw = a.view.x1 - a.view.x0;
 	for (uint32_t i = tid; i < VKR_TILE_PIX; i += 256) {
@@ -235,6 +256,13 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 		}
 		a.alphaTiles[tile] = flag;
 	}
+#ifdef VKR_WG_TIMES
+	WG_T(5);
+	if (tid == 0 && tile < 32768u) {
+		for (int k = 0; k < 6; k++) g_wgTimes[MODE][8 * tile + k] = wgT[k];
+		g_wgTimes[MODE][8 * tile + 6] = nO; g_wgTimes[MODE][8 * tile + 7] = n - nO;
+	}
+#endif
 }
 
 // ---------------------------------------------------------------------------
