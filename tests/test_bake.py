@@ -119,6 +119,27 @@ def test_zstd_decoder_rejects_damaged_frames():
         bake.zstd_decode(bytes(stored))
 
 
+def test_zstd_decoder_bounds_what_a_small_input_can_ask_for():
+    """Hand-made frames whose headers promise far more than they hold: rejected, and without the memory they claim."""
+    import resource
+    import struct
+    from vulkanrenderer_amd import bake
+    magic = struct.pack("<I", 0xFD2FB528)
+    # single-segment frame, 8-byte content size of 1.5 GiB, one raw block of 4 bytes
+    frame = magic + bytes([0xE0]) + struct.pack("<Q", 3 << 29) + struct.pack("<I", (4 << 3) | 1)[:3] + b"abcd"
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    with pytest.raises(bake.BakeError, match="content size"):
+        bake.zstd_decode(frame)
+    assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < (1 << 20)   # KiB: less than 1 GiB more
+    # an RLE block that claims 2 MiB (blocks regenerate at most 128 KiB)
+    frame = magic + bytes([0x00, 0x58]) + struct.pack("<I", ((2 << 20) - 1) << 3 | (1 << 1) | 1)[:3] + b"x"
+    with pytest.raises(bake.BakeError, match="128 KiB"):
+        bake.zstd_decode(frame)
+    # the largest legal RLE block is fine
+    frame = magic + bytes([0x00, 0x58]) + struct.pack("<I", (128 << 10) << 3 | (1 << 1) | 1)[:3] + b"x"
+    assert bake.zstd_decode(frame) == b"x" * (128 << 10)
+
+
 def test_baked_file_loads_in_the_reference_loader_format(tmp_path):
     """The writer's output passes the reader that mirrors load_baked_model (magic, variant, counts, no trailing bytes)
     and its packed TBN equals the packer that is pinned separately (test_pinned_fixtures)."""

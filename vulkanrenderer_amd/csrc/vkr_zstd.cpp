@@ -328,6 +328,8 @@ void decode_block(FrameState& st, const uint8_t* src, size_t len, std::vector<ui
 		else { if (pos + 1 > len) bad("truncated sequence count"); nseq = ((nseq - 128) << 8) + src[pos]; pos += 1; }
 	}
 	size_t litPos = 0;
+	const size_t blockStart = out.size();
+	const size_t kBlockMax = 128u << 10; // Block_Maximum_Size: no block regenerates more
 	if (nseq) {
 		if (pos >= len) bad("missing compression modes");
 		const int modes = src[pos++];
@@ -365,6 +367,7 @@ void decode_block(FrameState& st, const uint8_t* src, size_t len, std::vector<ui
 				}
 			}
 			if (litPos + llen > lit.size()) bad("sequence asks for more literals than the block holds");
+			if ((out.size() - blockStart) + llen + mlen > kBlockMax) bad("block regenerates more than the block maximum");
 			out.insert(out.end(), lit.begin() + litPos, lit.begin() + litPos + llen);
 			litPos += llen;
 			const size_t have = out.size() - frameStart;
@@ -441,7 +444,8 @@ size_t decode_frame(const uint8_t* src, size_t len, std::vector<uint8_t>& out)
 	if (single) windowSize = contentSize;
 	if (windowSize > ((uint64_t)1 << 31)) bad("window larger than 2 GiB");
 	const size_t frameStart = out.size();
-	if (fcsBytes && contentSize < ((uint64_t)1 << 32)) out.reserve(out.size() + (size_t)contentSize);
+	// a hint only, and a header can claim anything: never more than 256 MiB ahead of the data
+	if (fcsBytes) out.reserve(out.size() + (size_t)(contentSize < ((uint64_t)256 << 20) ? contentSize : ((uint64_t)256 << 20)));
 	FrameState st;
 	std::vector<uint8_t> lit;
 	for (;;) {
@@ -451,6 +455,7 @@ size_t decode_frame(const uint8_t* src, size_t len, std::vector<uint8_t>& out)
 		const int last = bh & 1, type = (bh >> 1) & 3;
 		const size_t size = bh >> 3;
 		if (type == 3) bad("reserved block type");
+		if (type != 2 && size > (128u << 10)) bad("block larger than 128 KiB");
 		if (type == 0) {
 			if (pos + size > len) bad("raw block runs past the input");
 			out.insert(out.end(), src + pos, src + pos + size);
