@@ -154,3 +154,42 @@ def test_random_soups_against_the_oracle(seed):
                     assert (ref["tri_id"] != 0xFFFFFFFF).mean() > 0.3
     finally:
         sc.close(); osc.close(); ctx.close()
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_partitions_of_random_soups_reassemble(seed):
+    """Bands, interleaved stripes, two frames in flight and the allocation-free entry point on the adversarial scenes:
+    every way of rendering the frame gives the bytes of the frame rendered in one piece (triangles that end on a
+    tile or stripe border, spikes through several shares, coplanar duplicates across shares)."""
+    from vulkanrenderer_amd import abi, renderer
+    from vulkanrenderer_amd.dist import band_rect, stripe_rows
+    W, H = [(200, 136), (333, 187), (160, 96)][seed % 3]
+    packed = fuzz_scene(seed, W, H, scale=2)
+    ctx = renderer.Context(0)
+    sc = renderer.Scene(ctx, packed)
+    try:
+        pose = pose_matrix(0.1, 0.1, -0.5, yaw=0.1 * (seed - 22))
+        for name, kw, want in (("deferred", dict(deferred=True), ("rgba8", "tri_id", "depth_bits")),
+                               ("forward", dict(debug=1, shadow_size=128), ("rgba8", "tri_id", "depth_bits")),
+                               ("overdraw", dict(debug=5), ("rgba8", "stencil")),
+                               ("overshade", dict(debug=6), ("rgba8", "stencil"))):
+            def params(**extra):
+                return abi.make_params(W, H, renderer.make_uniforms(W, H, pose, kw.get("debug", 1)), **dict(kw, **extra))
+            full = sc.render(params(), want=want)
+            for world, sh in ((3, 32), (5, 32)):
+                got = {k: np.zeros_like(v) for k, v in full.items()}
+                for r in range(world):
+                    rows = stripe_rows(H, world, r, sh)
+                    part = sc.render(params(stripes=abi.stripes(sh, world, r)), want=want)
+                    for k in want:
+                        got[k][rows] = part[k]
+                for k in want:
+                    assert np.array_equal(full[k], got[k]), "seed %d %s stripes/%d: %s" % (seed, name, world, k)
+            bands = [sc.render(params(rect=band_rect(r, 4, W, H)), want=want) for r in range(4)]
+            for k in want:
+                assert np.array_equal(np.concatenate([b[k] for b in bands]), full[k]), "seed %d %s bands: %s" % (seed, name, k)
+            static = sc.render(params(), want=want, static=True)
+            for k in want:
+                assert np.array_equal(static[k], full[k]), "seed %d %s allocation-free: %s" % (seed, name, k)
+    finally:
+        sc.close(); ctx.close()
