@@ -54,9 +54,103 @@ def write_pngs():
     Image.fromarray(np.full((1, 1, 4), 255, np.uint8), "RGBA").save(os.path.join(d, "one.png"))
 
 
+ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))  # x0, y0, dx, dy
+
+
+def encode_png(samples, depth, ctype, interlace, plte=None, trns=None, filters=(0, 1, 2, 3, 4)):
+    """A PNG writer for the fixtures (Pillow writes no interlaced files): `samples` is H x W x channels of raw sample
+    values; scanlines take the filter types of `filters` in turn."""
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    H, W, C = samples.shape
+    bpp = max(1, C * depth // 8)
+
+    def pack_row(row):  # row: w x C samples -> bytes
+        flat = row.reshape(-1).astype(np.uint32)
+        if depth == 16:
+            return b"".join(struct.pack(">H", int(v)) for v in flat)
+        if depth == 8:
+            return bytes(int(v) for v in flat)
+        out, acc, n = bytearray(), 0, 0
+        for v in flat:
+            acc = (acc << depth) | int(v); n += depth
+            if n == 8:
+                out.append(acc); acc, n = 0, 0
+        if n:
+            out.append(acc << (8 - n))
+        return bytes(out)
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+
+    def filtered(rows):  # packed rows of one (sub-)image -> filtered scanlines
+        out, prev = bytearray(), None
+        for y, cur in enumerate(rows):
+            ft = filters[y % len(filters)]
+            out.append(ft)
+            for i, v in enumerate(cur):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i] if prev is not None else 0
+                c = prev[i - bpp] if (prev is not None and i >= bpp) else 0
+                pred = (0, a, b, (a + b) >> 1, paeth(a, b, c))[ft]
+                out.append((v - pred) & 255)
+            prev = cur
+        return bytes(out)
+
+    if interlace:
+        raw = b""
+        for x0, y0, dx, dy in ADAM7:
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += filtered([pack_row(r) for r in sub])
+    else:
+        raw = filtered([pack_row(r) for r in samples])
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, 1 if interlace else 0))
+    if plte is not None:
+        png += chunk(b"PLTE", bytes(plte))
+    if trns is not None:
+        png += chunk(b"tRNS", bytes(trns))
+    half = len(zlib.compress(raw, 9)) // 2
+    z = zlib.compress(raw, 9)
+    return png + chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")   # two IDAT chunks on purpose
+
+
+def write_interlaced_pngs():
+    """Adam7 files of every kind the decoder handles, with sizes that leave some of the seven passes empty, every
+    scanline filter, and two non-interlaced files of kinds Pillow does not write (4-bit palette, 16-bit RGB with tRNS)."""
+    d = os.path.join(GOLD, "png")
+    rng = np.random.default_rng(12)
+
+    def put(name, *a, **k):
+        with open(os.path.join(d, name), "wb") as f:
+            f.write(encode_png(*a, **k))
+
+    put("adam7_rgba8.png", rng.integers(0, 256, (11, 13, 4)), 8, 6, True)
+    put("adam7_rgb8.png", rng.integers(0, 256, (8, 8, 3)), 8, 2, True)
+    put("adam7_grey1.png", rng.integers(0, 2, (5, 9, 1)), 1, 0, True)
+    put("adam7_grey2.png", rng.integers(0, 4, (7, 6, 1)), 2, 0, True)
+    put("adam7_pal4_trns.png", rng.integers(0, 16, (3, 7, 1)), 4, 3, True, plte=rng.integers(0, 256, 48).tolist(), trns=rng.integers(0, 256, 9).tolist())
+    put("adam7_rgb16_trns.png", np.concatenate([rng.integers(0, 65536, (9, 5, 3)), np.full((1, 5, 3), 4660)]), 16, 2, True, trns=[0x12, 0x34] * 3)
+    put("adam7_greyalpha8_1x1.png", rng.integers(0, 256, (1, 1, 2)), 8, 4, True)
+    put("adam7_greyalpha16_2x3.png", rng.integers(0, 65536, (3, 2, 2)), 16, 4, True)
+    put("adam7_grey8_3x1.png", rng.integers(0, 256, (1, 3, 1)), 8, 0, True)
+    put("adam7_rgba16_33x17.png", rng.integers(0, 65536, (17, 33, 4)), 16, 6, True)
+    put("pal4_trns.png", rng.integers(0, 16, (6, 5, 1)), 4, 3, False, plte=rng.integers(0, 256, 48).tolist(), trns=rng.integers(0, 256, 5).tolist())
+    put("rgb16_trns.png", np.concatenate([rng.integers(0, 65536, (4, 6, 3)), np.full((1, 6, 3), 513)]), 16, 2, False, trns=[0x02, 0x01] * 3)
+    put("grey4_trns.png", rng.integers(0, 16, (5, 5, 1)), 4, 0, False, trns=[0, 7])
+
+
 def main():
-    write_micro()
-    write_pngs()
+    if "--pngs-only" not in sys.argv:
+        write_micro()
+        write_pngs()
+    write_interlaced_pngs()
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/ref_fixtures missing: run `make -C oracle _ref` where /root/reference exists")
     with open(os.path.join(GOLD, "ref_loadmodel.json"), "w") as f:

@@ -64,7 +64,8 @@ int paeth(int a, int b, int c)
 	return c;
 }
 
-// Non-interlaced PNG -> RGBA8, flipped vertically.  Returns an empty string on success.
+// PNG (every colour type and bit depth, interlaced or not) -> RGBA8, flipped vertically, as stbi_load(path, ..., 4)
+// delivers it after stbi_set_flip_vertically_on_load(1).  Returns an empty string on success.
 std::string decode_png(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgba, uint32_t& W, uint32_t& H)
 {
 	static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
@@ -89,7 +90,7 @@ std::string decode_png(const std::vector<uint8_t>& file, std::vector<uint8_t>& r
 		off += 12 + (size_t)len;
 	}
 	if (!haveHdr || W == 0 || H == 0) return "missing IHDR";
-	if (interlace) return "interlaced PNG is not supported";
+	if (interlace > 1) return "bad interlace method";
 	int channels;
 	switch (ctype) {
 	case 0: channels = 1; break;
@@ -104,66 +105,94 @@ std::string decode_png(const std::vector<uint8_t>& file, std::vector<uint8_t>& r
 	if ((depth < 8 && ctype != 0 && ctype != 3) || (depth == 16 && ctype == 3)) return "bad bit depth for the colour type";
 	if (W > (1u << 24) || H > (1u << 24)) return "image too large"; // stb_image's own limit (STBI_MAX_DIMENSIONS)
 	const size_t bpp = (size_t)channels * depth;           // bits per pixel
-	const size_t stride = ((size_t)W * bpp + 7) / 8;       // bytes per row
 	const size_t fbpp = (bpp + 7) / 8;                     // filter distance in bytes
-	std::vector<uint8_t> raw((stride + 1) * (size_t)H);
+	// The image as the scanlines are stored: in one piece, or as the seven reduced images of Adam7 interlacing (pass p
+	// holds the pixels (x0 + i dx, y0 + j dy); empty passes are not stored), each filtered on its own.
+	struct Pass { uint32_t x0, y0, dx, dy, w, h; size_t stride; };
+	static const uint32_t kAdam7[7][4] = { { 0, 0, 8, 8 }, { 4, 0, 8, 8 }, { 0, 4, 4, 8 }, { 2, 0, 4, 4 }, { 0, 2, 2, 4 }, { 1, 0, 2, 2 }, { 0, 1, 1, 2 } };
+	Pass passes[7];
+	int nPasses = 0;
+	size_t rawSize = 0;
+	for (int p = 0; p < (interlace ? 7 : 1); p++) {
+		Pass q;
+		if (interlace) { q.x0 = kAdam7[p][0]; q.y0 = kAdam7[p][1]; q.dx = kAdam7[p][2]; q.dy = kAdam7[p][3]; }
+		else { q.x0 = q.y0 = 0; q.dx = q.dy = 1; }
+		q.w = (W - q.x0 + q.dx - 1) / q.dx; q.h = (H - q.y0 + q.dy - 1) / q.dy;
+		if (W <= q.x0 || H <= q.y0 || !q.w || !q.h) continue;
+		q.stride = ((size_t)q.w * bpp + 7) / 8;
+		rawSize += (q.stride + 1) * (size_t)q.h;
+		passes[nPasses++] = q;
+	}
+	// deflate expands at most about 1032 times: a header that promises more than the data can hold is refused before
+	// anything of that size is allocated
+	if (rawSize / 1100 > idat.size() + 16) return "image data too short for the image size";
+	std::vector<uint8_t> raw(rawSize);
 	uLongf rawLen = (uLongf)raw.size();
 	if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size()) return "zlib inflate failed";
-	std::vector<uint8_t> img(stride * (size_t)H);
-	for (uint32_t y = 0; y < H; y++) {
-		const uint8_t ft = raw[(stride + 1) * y];
-		const uint8_t* src = &raw[(stride + 1) * y + 1];
-		uint8_t* cur = &img[stride * y];
-		const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
-		for (size_t i = 0; i < stride; i++) {
-			int a = i >= fbpp ? cur[i - fbpp] : 0, b = up ? up[i] : 0, c = (up && i >= fbpp) ? up[i - fbpp] : 0;
-			int v = src[i];
-			switch (ft) {
-			case 0: break;
-			case 1: v += a; break;
-			case 2: v += b; break;
-			case 3: v += (a + b) >> 1; break;
-			case 4: v += paeth(a, b, c); break;
-			default: return "bad filter type";
-			}
-			cur[i] = (uint8_t)v;
-		}
-	}
 	rgba.resize((size_t)W * H * 4);
 	const uint32_t maxv = (1u << depth) - 1u;
-	for (uint32_t y = 0; y < H; y++) {
-		const uint8_t* row = &img[stride * y];
-		uint8_t* dst = &rgba[(size_t)(H - 1 - y) * W * 4]; // vertical flip
-		for (uint32_t x = 0; x < W; x++) {
-			uint32_t s[4] = { 0, 0, 0, 0 }; // raw samples
-			for (int ch = 0; ch < channels; ch++) {
-				const size_t bit = ((size_t)x * channels + ch) * depth;
-				if (depth == 8) s[ch] = row[bit >> 3];
-				else if (depth == 16) s[ch] = ((uint32_t)row[bit >> 3] << 8) | row[(bit >> 3) + 1];
-				else s[ch] = (row[bit >> 3] >> (8 - depth - (bit & 7))) & maxv;
+	auto to8 = [&](uint32_t v) -> uint8_t {
+		if (depth == 16) return (uint8_t)(v >> 8);
+		if (depth == 8) return (uint8_t)v;
+		return (uint8_t)(v * (255u / maxv));
+	};
+	std::vector<uint8_t> img;
+	size_t rawAt = 0;
+	for (int p = 0; p < nPasses; p++) {
+		const Pass& q = passes[p];
+		const size_t stride = q.stride;
+		img.assign(stride * (size_t)q.h, 0);
+		for (uint32_t y = 0; y < q.h; y++) {
+			const uint8_t ft = raw[rawAt + (stride + 1) * y];
+			const uint8_t* src = &raw[rawAt + (stride + 1) * y + 1];
+			uint8_t* cur = &img[stride * y];
+			const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+			if (ft > 4) return "bad filter type";
+			for (size_t i = 0; i < stride; i++) {
+				int a = i >= fbpp ? cur[i - fbpp] : 0, b = up ? up[i] : 0, c = (up && i >= fbpp) ? up[i - fbpp] : 0;
+				int v = src[i];
+				switch (ft) {
+				case 0: break;
+				case 1: v += a; break;
+				case 2: v += b; break;
+				case 3: v += (a + b) >> 1; break;
+				default: v += paeth(a, b, c); break;
+				}
+				cur[i] = (uint8_t)v;
 			}
-			uint8_t r, g, b, a = 255;
-			auto to8 = [&](uint32_t v) -> uint8_t {
-				if (depth == 16) return (uint8_t)(v >> 8);
-				if (depth == 8) return (uint8_t)v;
-				return (uint8_t)(v * (255u / maxv));
-			};
-			if (ctype == 3) {
-				const uint32_t idx = s[0];
-				if ((size_t)idx * 3 + 2 < plte.size()) { r = plte[idx * 3]; g = plte[idx * 3 + 1]; b = plte[idx * 3 + 2]; }
-				else { r = g = b = 0; }
-				if (idx < trns.size()) a = trns[idx];
-			} else if (ctype == 0 || ctype == 4) {
-				r = g = b = to8(s[0]);
-				if (ctype == 4) a = to8(s[1]);
-				else if (trns.size() >= 2 && s[0] == (((uint32_t)trns[0] << 8) | trns[1])) a = 0;
-			} else {
-				r = to8(s[0]); g = to8(s[1]); b = to8(s[2]);
-				if (ctype == 6) a = to8(s[3]);
-				else if (trns.size() >= 6 && s[0] == (((uint32_t)trns[0] << 8) | trns[1]) &&
-				         s[1] == (((uint32_t)trns[2] << 8) | trns[3]) && s[2] == (((uint32_t)trns[4] << 8) | trns[5])) a = 0;
+		}
+		rawAt += (stride + 1) * (size_t)q.h;
+		for (uint32_t y = 0; y < q.h; y++) {
+			const uint8_t* row = &img[stride * y];
+			const uint32_t oy = q.y0 + y * q.dy;
+			uint8_t* dst = &rgba[(size_t)(H - 1 - oy) * W * 4]; // vertical flip
+			for (uint32_t x = 0; x < q.w; x++) {
+				uint32_t s[4] = { 0, 0, 0, 0 }; // raw samples
+				for (int ch = 0; ch < channels; ch++) {
+					const size_t bit = ((size_t)x * channels + ch) * depth;
+					if (depth == 8) s[ch] = row[bit >> 3];
+					else if (depth == 16) s[ch] = ((uint32_t)row[bit >> 3] << 8) | row[(bit >> 3) + 1];
+					else s[ch] = (row[bit >> 3] >> (8 - depth - (bit & 7))) & maxv;
+				}
+				uint8_t r, g, b, a = 255;
+				if (ctype == 3) {
+					const uint32_t idx = s[0];
+					if ((size_t)idx * 3 + 2 < plte.size()) { r = plte[idx * 3]; g = plte[idx * 3 + 1]; b = plte[idx * 3 + 2]; }
+					else { r = g = b = 0; }
+					if (idx < trns.size()) a = trns[idx];
+				} else if (ctype == 0 || ctype == 4) {
+					r = g = b = to8(s[0]);
+					if (ctype == 4) a = to8(s[1]);
+					else if (trns.size() >= 2 && s[0] == (((uint32_t)trns[0] << 8) | trns[1])) a = 0;
+				} else {
+					r = to8(s[0]); g = to8(s[1]); b = to8(s[2]);
+					if (ctype == 6) a = to8(s[3]);
+					else if (trns.size() >= 6 && s[0] == (((uint32_t)trns[0] << 8) | trns[1]) &&
+					         s[1] == (((uint32_t)trns[2] << 8) | trns[3]) && s[2] == (((uint32_t)trns[4] << 8) | trns[5])) a = 0;
+				}
+				const size_t ox = q.x0 + (size_t)x * q.dx;
+				dst[4 * ox + 0] = r; dst[4 * ox + 1] = g; dst[4 * ox + 2] = b; dst[4 * ox + 3] = a;
 			}
-			dst[4 * x + 0] = r; dst[4 * x + 1] = g; dst[4 * x + 2] = b; dst[4 * x + 3] = a;
 		}
 	}
 	return "";
