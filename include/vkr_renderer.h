@@ -23,6 +23,7 @@
 #ifndef VKR_RENDERER_H
 #define VKR_RENDERER_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -349,6 +350,14 @@ VKR_API int vkr_profile_get(vkr_context* ctx, int stage, double* total_ms, uint6
 /* The HIP stream (hipStream_t) the context launches on, and its device. */
 VKR_API void* vkr_context_stream(vkr_context* ctx);
 VKR_API int vkr_context_device(vkr_context* ctx);
+
+/* Device memory for a host that has no HIP of its own (a plain C program): buffers on the context's GPU to render
+ * into (vkr_frame_out accepts device pointers) and to exchange with vkr_composite_gather, and a copy in either
+ * direction that is ordered behind everything queued on the context's stream and complete on return.
+ * Replaces: lut::create_buffer + the staging copies of the reference (utils/vkbuffer.cpp:49-69, utils/vkimage.cpp:76-143). */
+VKR_API int vkr_device_malloc(vkr_context* ctx, size_t bytes, void** out);
+VKR_API void vkr_device_free(vkr_context* ctx, void* ptr);
+VKR_API int vkr_device_copy(vkr_context* ctx, void* dst, const void* src, size_t bytes);
 
 #ifdef __cplusplus
 }

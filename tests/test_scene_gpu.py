@@ -318,6 +318,15 @@ def test_c_host_renders_the_same_frames(ctx, tmp_path):
         got = renderer.decode_png(png)[::-1]  # the decoder returns rows bottom first
         ref = sc.render(params(W, H, bench.fly_pose(3 + 6), shadow=2048, **kw), want=("rgba8",))["rgba8"]  # the host leaves shadow_size 0 = 2048
         assert np.array_equal(got, ref), mode
+    # the same host as one rank of a sort-first run: its rows rendered into device memory, gathered by the RCCL
+    # compositor (a communicator of one rank), read back and written out - bands and interleaved stripes
+    ref = sc.render(params(W, H, bench.fly_pose(3 + 6), shadow=2048, deferred=True), want=("rgba8",))["rgba8"]
+    for stripe in (0, 32):
+        png, uid = str(tmp_path / ("sf%d.png" % stripe)), str(tmp_path / ("uid%d" % stripe))
+        r = subprocess.run([exe, scene_path, "--width", str(W), "--height", str(H), "--frames", "7", "--first", "3", "--mode", "deferred", "--png", png,
+                            "--ranks", "1", "--rank", "0", "--uid-file", uid, "--stripe-height", str(stripe)], capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0 and '"ranks": 1' in r.stdout, (r.returncode, r.stdout, r.stderr)
+        assert np.array_equal(renderer.decode_png(png)[::-1], ref), "sort-first host, stripe height %d" % stripe
     sc.close()
 
 

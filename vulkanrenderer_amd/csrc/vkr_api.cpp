@@ -577,6 +577,32 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 extern "C" void* vkr_context_stream(vkr_context* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int vkr_context_device(vkr_context* c) { return c ? c->device : -1; }
 
+extern "C" int vkr_device_malloc(vkr_context* c, size_t bytes, void** out)
+{
+	if (!c || !out) return set_error(VKR_E_INVALID, "vkr_device_malloc: NULL argument");
+	*out = nullptr;
+	HIP_CHECK(hipSetDevice(c->device));
+	hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+	if (e != hipSuccess) { *out = nullptr; return set_error(VKR_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+	return VKR_OK;
+}
+
+extern "C" void vkr_device_free(vkr_context* c, void* ptr)
+{
+	if (!c || !ptr) return;
+	(void)hipSetDevice(c->device);
+	(void)hipFree(ptr);
+}
+
+extern "C" int vkr_device_copy(vkr_context* c, void* dst, const void* src, size_t bytes)
+{
+	if (!c || (bytes && (!dst || !src))) return set_error(VKR_E_INVALID, "vkr_device_copy: NULL argument");
+	HIP_CHECK(hipSetDevice(c->device));
+	if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
+	HIP_CHECK(hipStreamSynchronize(c->stream));
+	return VKR_OK;
+}
+
 // ---------------------------------------------------------------------------
 // profiling
 // ---------------------------------------------------------------------------

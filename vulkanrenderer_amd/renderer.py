@@ -27,6 +27,7 @@ EXPORTS = [
     "vkr_wait_next_lane", "vkr_user_state_key", "vkr_user_state_button", "vkr_user_state_motion",
     "vkr_frame_params_set_modes", "vkr_render_static", "vkr_context_device", "vkr_sortfirst_rows",
     "vkr_composite_unique_id", "vkr_compositor_create", "vkr_compositor_destroy", "vkr_composite_gather",
+    "vkr_device_malloc", "vkr_device_free", "vkr_device_copy",
 ]
 
 
