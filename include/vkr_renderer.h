@@ -334,6 +334,10 @@ VKR_API void vkr_compositor_destroy(vkr_compositor* c);
  * (local == frame + first_row * width * 4) is not copied. */
 VKR_API int vkr_composite_gather(vkr_compositor* c, uint32_t width, uint32_t height, uint32_t stripe_height, const void* local,
                                  void* frame, int root);
+/* The same exchange for rows of any size: the side buffers of a frame (tri_id and depth_bits are 4 bytes per pixel,
+ * mip_level and stencil 1, the G-buffer attachments 8) travel like the image. */
+VKR_API int vkr_composite_gather_rows(vkr_compositor* c, size_t row_bytes, uint32_t height, uint32_t stripe_height, const void* local,
+                                      void* frame, int root);
 
 /* ---- measurement ---- */
 

@@ -83,5 +83,26 @@ def test_rccl_compositor_with_one_rank(scene):
         comp.gather(W, H, frame.ptr, frame.ptr, root=0)
         ctx.wait()
         assert np.array_equal(frame.numpy((H, W, 4), np.uint8), ref)
+        # the integer side buffers travel the same way: triangle ids (4 bytes per pixel) and the overdraw counter (1)
+        side = sc.render(make(W, H, IDENTITY, debug=5), want=("stencil",))["stencil"]
+        ids = sc.render(make(W, H, IDENTITY, deferred=True), want=("tri_id",))["tri_id"]
+        lstc, fstc = DeviceBuffer(W * H), DeviceBuffer(W * H)
+        try:
+            fo = abi.FrameOut()
+            fo.tri_id = local.ptr
+            frame.zero()
+            sc.submit(make(W, H, IDENTITY, deferred=True), fo)
+            comp.gather_rows(W * 4, H, local.ptr, frame.ptr, root=0, stripe_height=32)
+            ctx.wait()
+            assert np.array_equal(frame.numpy((H, W), np.uint32), ids)
+            fo = abi.FrameOut()
+            fo.stencil = lstc.ptr
+            fstc.zero()
+            sc.submit(make(W, H, IDENTITY, debug=5), fo)
+            comp.gather_rows(W, H, lstc.ptr, fstc.ptr, root=-1)
+            ctx.wait()
+            assert np.array_equal(fstc.numpy((H, W), np.uint8), side)
+        finally:
+            lstc.free(); fstc.free()
     finally:
         comp.close(); local.free(); frame.free()

@@ -168,14 +168,20 @@ extern "C" void vkr_compositor_destroy(vkr_compositor* c)
 extern "C" int vkr_composite_gather(vkr_compositor* c, uint32_t width, uint32_t height, uint32_t stripe_height, const void* local,
                                     void* frame, int root)
 {
-	if (!c || !width || !height) return vkr_set_error_ext(VKR_E_INVALID, "vkr_composite_gather: bad argument");
+	return vkr_composite_gather_rows(c, (size_t)width * 4, height, stripe_height, local, frame, root);
+}
+
+extern "C" int vkr_composite_gather_rows(vkr_compositor* c, size_t row_bytes, uint32_t height, uint32_t stripe_height, const void* local,
+                                         void* frame, int root)
+{
+	if (!c || !row_bytes || !height) return vkr_set_error_ext(VKR_E_INVALID, "vkr_composite_gather: bad argument");
 	if (root >= c->world) return vkr_set_error_ext(VKR_E_INVALID, "vkr_composite_gather: root %d of %d", root, c->world);
 	const bool receiver = root < 0 || root == c->rank;
 	if (receiver && !frame) return vkr_set_error_ext(VKR_E_INVALID, "vkr_composite_gather: this rank receives the frame but `frame` is NULL");
 	if (!local) return vkr_set_error_ext(VKR_E_INVALID, "vkr_composite_gather: `local` is NULL");
 	if (hipSetDevice(c->device) != hipSuccess) return vkr_set_error_ext(VKR_E_DEVICE, "hipSetDevice(%d) failed", c->device);
 	hipStream_t stream = (hipStream_t)vkr_context_stream(c->ctx);
-	const size_t rowBytes = (size_t)width * 4;
+	const size_t rowBytes = row_bytes;
 	const uint32_t W = (uint32_t)c->world;
 	const uint32_t runH = stripe_height ? stripe_height : 0;
 	RCCL_CHECK(g_rccl.GroupStart());

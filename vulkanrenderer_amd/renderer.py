@@ -27,7 +27,7 @@ EXPORTS = [
     "vkr_wait_next_lane", "vkr_user_state_key", "vkr_user_state_button", "vkr_user_state_motion",
     "vkr_frame_params_set_modes", "vkr_render_static", "vkr_context_device", "vkr_sortfirst_rows",
     "vkr_composite_unique_id", "vkr_compositor_create", "vkr_compositor_destroy", "vkr_composite_gather",
-    "vkr_device_malloc", "vkr_device_free", "vkr_device_copy",
+    "vkr_device_malloc", "vkr_device_free", "vkr_device_copy", "vkr_composite_gather_rows",
 ]
 
 
@@ -93,6 +93,7 @@ def lib():
         L.vkr_compositor_destroy.argtypes = [C.c_void_p]
         L.vkr_compositor_destroy.restype = None
         L.vkr_composite_gather.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+        L.vkr_composite_gather_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
         L.vkr_wait_next_lane.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -211,6 +212,10 @@ class Compositor:
 
     def gather(self, width, height, local_ptr, frame_ptr, root=0, stripe_height=0):
         _check(lib().vkr_composite_gather(self.h, width, height, stripe_height, local_ptr, frame_ptr, root))
+
+    def gather_rows(self, row_bytes, height, local_ptr, frame_ptr, root=0, stripe_height=0):
+        """The same exchange for a side buffer: rows of `row_bytes` bytes (tri_id: 4 per pixel, stencil: 1, ...)."""
+        _check(lib().vkr_composite_gather_rows(self.h, row_bytes, height, stripe_height, local_ptr, frame_ptr, root))
 
     def close(self):
         if self.h:
