@@ -357,8 +357,23 @@ __device__ __forceinline__ float alpha_fetch_finish(const AlphaFetch& f, const A
 
 #define ALPHA_PARTS 1 // wavefronts that share one 8x8 block, each taking every fourth staged entry
 
+#ifdef VKR_WG_TIMES
+__device__ unsigned long long g_alphaTimes[8 * 65536];
+extern "C" __attribute__((visibility("default"))) int vkr_debug_alpha_times(void* dst, size_t bytes)
+{
+	return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_alphaTimes), bytes, 0, hipMemcpyDeviceToHost);
+}
+#define AT_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atAcc[k] += t_ - atLast; atLast = t_; } } while (0)
+#else
+#define AT_MARK(k)
+#endif
+
 __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a)
 {
+#ifdef VKR_WG_TIMES
+	unsigned long long atAcc[5] = { 0, 0, 0, 0, 0 }, atLast = wall_clock64();
+	const unsigned long long atStart = atLast;
+#endif
 	// Workgroups [0, 4 * tiles): one per quadrant.  Behind them ALPHA_HELPERS workgroups: (ALPHA_SPLIT - 1) per
 	// quadrant of the first deep tiles.  The entries of a deep tile's bin section are dealt round-robin to the
 	// ALPHA_SPLIT workgroups of a quadrant, each resolves its share from the same starting keys, and the shares
@@ -424,6 +439,7 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 	const uint32_t nAll = end - beg;
 	const uint32_t n = (nAll + split - 1u - sub) / split; // this workgroup's share: entries sub, sub + split, ...
 
+	AT_MARK(0); // header, seed keys
 	for (uint32_t base = 0; base < n; base += ALPHA_STAGE) {
 		if (tid == 0) sCount = 0;
 		__syncthreads();
@@ -460,6 +476,7 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 			}
 		}
 		__syncthreads();
+		AT_MARK(1); // staging
 		const uint32_t m = sCount;
 		// Near entries first, so that what lies behind them fails the depth test before its alpha test: each
 		// staged entry finds its rank by counting the entries in front of it.  The order changes the work, not
@@ -512,6 +529,7 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 			}
 			__syncthreads();
 		}
+		AT_MARK(2); // ranking + per-block lists
 		// Entries are taken two at a time: the second one's coverage and depth test run against the key as it
 		// is before the first one's alpha test (a fragment tested needlessly cannot change the minimum), so both
 		// fragments' texel loads are in flight together.
@@ -590,6 +608,7 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 		// the block's wavefronts agree on the nearest key found so far
 		sKey[part][blk][lane] = key;
 		__syncthreads(); // also: the stage is rewritten by the next chunk
+		AT_MARK(3); // the walk (until the slowest wavefront of the workgroup is through)
 		{
 			unsigned long long k = key;
 #pragma unroll
@@ -602,6 +621,13 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 		if (split > 1u) atomicMin(&a.vis[p], key);
 		else a.vis[p] = key;
 	}
+#ifdef VKR_WG_TIMES
+	AT_MARK(4);
+	if (tid == 0 && blockIdx.x < 65536u) {
+		for (int k = 0; k < 5; k++) g_alphaTimes[8 * blockIdx.x + k] = atAcc[k];
+		g_alphaTimes[8 * blockIdx.x + 5] = atStart; g_alphaTimes[8 * blockIdx.x + 6] = nAll; g_alphaTimes[8 * blockIdx.x + 7] = 1;
+	}
+#endif
 }
 
 // ---------------------------------------------------------------------------
