@@ -166,7 +166,9 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 	// lane nine lanes in ten would idle.  The lanes of a group take every group-th column of the bounding box.
 	const uint32_t logG = n <= 64u ? 2u : n <= 128u ? 1u : 0u, G = 1u << logG;
 	const uint32_t sub = lane & (G - 1u);
+#ifdef VKR_WG_TIMES
 	if (n == 0xffffffffu) return; // never: makes the header loads complete before the clock is read
+#endif
 	WG_T(2);
 	for (uint32_t base = 0; base < n; base += 256u >> logG) {
 		// entries are dealt to the four wavefronts round-robin, so a short bin still spreads its
