@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -38,8 +39,11 @@ struct Rccl {
 
 Rccl g_rccl;
 
+std::mutex g_rcclLock;
+
 int load_rccl()
 {
+	std::lock_guard<std::mutex> guard(g_rcclLock); // contexts of several host threads may create their compositors at once
 	if (g_rccl.lib) return VKR_OK;
 	// The RCCL that belongs to the HIP runtime this process runs on: a process can hold two ROCm installations (PyTorch
 	// ships a HIP runtime and an RCCL of its own; whichever runtime was loaded first serves everybody), and a
