@@ -33,6 +33,8 @@ def lib():
         L.ora_scene_destroy.argtypes = [C.c_void_p]
         L.ora_render.argtypes = [C.c_void_p, C.POINTER(abi.FrameParams), C.POINTER(abi.FrameOut)]
         L.ora_render_rows.argtypes = [C.c_void_p, C.POINTER(abi.FrameParams), C.POINTER(abi.FrameOut), C.c_uint32, C.c_uint32]
+        L.ora_render_bands.argtypes = [C.c_void_p, C.POINTER(abi.FrameParams), C.POINTER(abi.FrameOut), C.c_uint32]
+        L.ora_set_band_threads.argtypes = [C.c_int]
         L.ora_texture_level.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.ora_make_uniforms.argtypes = [C.POINTER(abi.Uniforms), C.c_uint32, C.c_uint32,
@@ -106,8 +108,8 @@ class OracleScene:
 
     def render(self, params, want=("rgba8", "tri_id", "depth_bits", "mip_level", "stencil", "gbuf_normal",
                                    "gbuf_albedo", "shadow_map"), threads=1):
-        """threads > 1: the frame is cut into horizontal bands rendered concurrently (ora_render_rows; the C
-        call releases the GIL); the result is the same frame."""
+        """threads > 1: the frame is drawn as horizontal bands shared by that many threads (ora_render_bands: vertices
+        transformed and the light's depth map drawn once, every band its own rows); the result is the same frame."""
         W, H = params.width, params.height
         S = params.shadow_size or 2048
         bufs = {
@@ -124,18 +126,12 @@ class OracleScene:
                 setattr(out, k, v.ctypes.data)
         if threads <= 1:
             rc = lib().ora_render(self.h, C.byref(params), C.byref(out))
-            if rc:
-                raise RuntimeError("ora_render failed: %d" % rc)
         else:
-            from concurrent.futures import ThreadPoolExecutor
+            lib().ora_set_band_threads(int(threads))
             # more bands than threads: the cost of a band depends on what it shows
-            nb = min(H, threads * 4)
-            edges = [H * i // nb for i in range(nb + 1)]
-            fn = lib().ora_render_rows
-            with ThreadPoolExecutor(max_workers=threads) as ex:
-                rcs = list(ex.map(lambda i: fn(self.h, C.byref(params), C.byref(out), edges[i], edges[i + 1]), range(nb)))
-            if any(rcs):
-                raise RuntimeError("ora_render_rows failed: %s" % rcs)
+            rc = lib().ora_render_bands(self.h, C.byref(params), C.byref(out), max(8, -(-H // (threads * 4))))
+        if rc:
+            raise RuntimeError("oracle render failed: %d" % rc)
         return {k: v for k, v in bufs.items() if k in want}
 
 

@@ -908,6 +908,12 @@ typedef struct {
 	uint16_t* gN; uint16_t* gA; /* W*H*4 halfs */
 	float* shadow; uint32_t S;  /* S*S */
 	float lightMat[16];         /* biasMat * depthMVP */
+	/* set by ora_render_bands, which draws one frame as many row ranges: what every range would otherwise compute
+	 * for itself (clip-space vertices per mesh for the camera, the finished light depth map); NULL otherwise */
+	float* const* sharedClip;
+	float* const* sharedClipLight; /* the same under the light's matrix */
+	int sharedShadow;
+	uint32_t ly0, ly1;  /* rows [ly0, ly1) of the light depth map a PIPE_SHADOW draw may write (0, S: all) */
 	/* per draw */
 	const OraMesh* mesh;
 	const float* clip; /* V*4 for current mesh */
@@ -1155,12 +1161,28 @@ static void shade_debug(const Frame* f, int px, int py, float z, float out[4], u
 /* ------------------------------------------------------------------------ */
 /* rasterisation of one primitive                                            */
 /* ------------------------------------------------------------------------ */
+/* A row range's cheap test in front of the triangle set-up: 1 when the triangle cannot touch rows [r0, r1).
+ * With every w > 0 the clipped polygon lies inside the projected triangle, so the projected vertices bound its
+ * rows; one pixel of slack covers the snapping.  Anything else is left to the set-up. */
+static int rows_missed(const float* c0, const float* c1, const float* c2, uint32_t H, uint32_t r0, uint32_t r1)
+{
+	if (!(c0[3] > 0.0f && c1[3] > 0.0f && c2[3] > 0.0f)) return 0;
+	const double h = (double)H * 0.5;
+	const double y0 = ((double)c0[1] / (double)c0[3] + 1.0) * h, y1 = ((double)c1[1] / (double)c1[3] + 1.0) * h,
+	             y2 = ((double)c2[1] / (double)c2[3] + 1.0) * h;
+	if (!(y0 == y0) || !(y1 == y1) || !(y2 == y2)) return 0;
+	const double lo = fmin(y0, fmin(y1, y2)), hi = fmax(y0, fmax(y1, y2));
+	return hi < (double)r0 - 1.0 || lo > (double)r1 + 1.0;
+}
+
 static void raster_prim(Frame* f, int cull, uint32_t W, uint32_t H)
 {
 	SubTri st[8];
 	const float* c0 = f->clip + 4 * (size_t)f->i0;
 	const float* c1 = f->clip + 4 * (size_t)f->i1;
 	const float* c2 = f->clip + 4 * (size_t)f->i2;
+	const uint32_t r0 = (f->pipe == PIPE_SHADOW) ? f->ly0 : f->sy0, r1 = (f->pipe == PIPE_SHADOW) ? f->ly1 : f->sy1;
+	if ((r0 > 0 || r1 < H) && rows_missed(c0, c1, c2, H, r0, r1)) return;
 	int n = tri_setup(c0, c1, c2, W, H, cull, &f->pl, st);
 	for (int k = 0; k < n; k++) {
 		const SubTri* s = &st[k];
@@ -1175,10 +1197,8 @@ static void raster_prim(Frame* f, int cull, uint32_t W, uint32_t H)
 		if (px0 < 0) px0 = 0; if (py0 < 0) py0 = 0;
 		if (px1 > (int64_t)W - 1) px1 = (int64_t)W - 1;
 		if (py1 > (int64_t)H - 1) py1 = (int64_t)H - 1;
-		if (f->pipe != PIPE_SHADOW) {
-			if (py0 < (int64_t)f->sy0) py0 = (int64_t)f->sy0;
-			if (py1 > (int64_t)f->sy1 - 1) py1 = (int64_t)f->sy1 - 1;
-		}
+		if (py0 < (int64_t)r0) py0 = (int64_t)r0;
+		if (py1 > (int64_t)r1 - 1) py1 = (int64_t)r1 - 1;
 		if (px0 > px1 || py0 > py1) continue;
 		/* edge i: from vertex i to vertex (i+1)%3; E = dx*(py-y) - dy*(px-x) */
 		int64_t dx[3], dy[3]; int tl[3];
@@ -1269,16 +1289,19 @@ static void draw_range(Frame* f, const OraPrim* order, uint64_t first, uint64_t 
                        int cullAlpha, uint32_t W, uint32_t H)
 {
 	const ora_scene* sc = f->sc;
+	float* const* shared = (f->pipe == PIPE_SHADOW) ? f->sharedClipLight : f->sharedClip;
 	/* transform every mesh once */
 	float** clip = (float**)calloc(sc->nMesh ? sc->nMesh : 1, sizeof(float*));
 	for (uint64_t i = first; i < last; i++) {
 		uint32_t mi = order[i].mesh;
 		const OraMesh* m = &sc->mesh[mi];
-		if (!clip[mi]) {
+		if (shared) {
+			f->mesh = m; f->clip = shared[mi];
+		} else if (!clip[mi]) {
 			clip[mi] = (float*)malloc(sizeof(float) * 4 * (m->V ? m->V : 1));
 			for (uint32_t v = 0; v < m->V; v++) xform(M, m->pos + 3 * (size_t)v, clip[mi] + 4 * (size_t)v);
 		}
-		f->mesh = m; f->clip = clip[mi];
+		if (!shared) { f->mesh = m; f->clip = clip[mi]; }
 		f->i0 = m->idx[3 * (size_t)order[i].tri + 0];
 		f->i1 = m->idx[3 * (size_t)order[i].tri + 1];
 		f->i2 = m->idx[3 * (size_t)order[i].tri + 2];
@@ -1341,13 +1364,13 @@ static void deferred_light_pass(Frame* f)
 }
 
 /* postProcess.frag:9-25 with the default sampler on the offscreen
- * R8G8B8A8_SRGB image (main/main.cpp:1607, 3216). */
-static void mosaic_pass(const uint8_t* src, uint8_t* dst, uint32_t W, uint32_t H)
+ * R8G8B8A8_SRGB image (main/main.cpp:1607, 3216); rows [r0, r1) of the result. */
+static void mosaic_pass(const uint8_t* src, uint8_t* dst, uint32_t W, uint32_t H, uint32_t r0, uint32_t r1)
 {
 	float sx = (float)W, sy = (float)H;
 	float kw = 5.0f / sx, kh = 3.0f / sy;
 	float ox = 0.5f / sx, oy = 0.5f / sy;
-	for (uint32_t py = 0; py < H; py++)
+	for (uint32_t py = r0; py < r1; py++)
 		for (uint32_t px = 0; px < W; px++) {
 			float u = ((float)px + 0.5f) / sx, v = ((float)py + 0.5f) / sy;
 			float su = kw * floorf(u / kw), sv = kh * floorf(v / kh);
@@ -1371,12 +1394,22 @@ static void mosaic_pass(const uint8_t* src, uint8_t* dst, uint32_t W, uint32_t H
 		}
 }
 
-static void fill_colour(uint8_t* rgba, size_t n, float r, float g, float b, float a)
+/* rows [sy0, sy1) of the colour attachment */
+static void fill_colour_rows(Frame* f, float r, float g, float b, float a)
 {
 	float c[4] = { r, g, b, a };
 	uint8_t px[4];
 	write_colour(px, c);
-	for (size_t i = 0; i < n; i++) memcpy(rgba + i * 4, px, 4);
+	for (size_t i = (size_t)f->sy0 * f->W; i < (size_t)f->sy1 * f->W; i++) memcpy(f->rgba + i * 4, px, 4);
+}
+
+/* The light's depth pass (main/main.cpp:3950-3984): rows [ly0, ly1) of the map, opaque meshes only. */
+static void shadow_pass(Frame* f)
+{
+	const ora_scene* sc = f->sc;
+	for (size_t i = (size_t)f->ly0 * f->S; i < (size_t)f->ly1 * f->S; i++) f->shadow[i] = 1.0f;
+	f->pipe = PIPE_SHADOW;
+	draw_range(f, sc->orderA, 0, sc->nPrimOpaque, f->fp->uniforms.depthMVPUniform.depthMVP, 0, 0, f->S, f->S);
 }
 
 /* Shadow pass (main/main.cpp:3950-3984) followed by the regular pass
@@ -1385,22 +1418,26 @@ static void forward_passes(Frame* f)
 {
 	const ora_scene* sc = f->sc;
 	const vkr_uniforms* u = &f->fp->uniforms;
-	for (size_t i = 0; i < (size_t)f->S * f->S; i++) f->shadow[i] = 1.0f;
-	f->pipe = PIPE_SHADOW;
-	draw_range(f, sc->orderA, 0, sc->nPrimOpaque, u->depthMVPUniform.depthMVP, 0, 0, f->S, f->S);
+	if (!f->sharedShadow) shadow_pass(f);
 	/* biasMat * depthMVP, default.vert:46-50,83 */
 	static const float biasMat[16] = { 0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 1.0f, 0, 0.5f, 0.5f, 0, 1.0f };
 	mat4_mul(biasMat, u->depthMVPUniform.depthMVP, f->lightMat);
-	fill_colour(f->rgba, (size_t)f->W * f->H, 0.1f, 0.1f, 0.1f, 1.0f);
+	fill_colour_rows(f, 0.1f, 0.1f, 0.1f, 1.0f);
 	f->pipe = PIPE_FORWARD;
 	draw_range(f, sc->orderA, 0, sc->nPrim, u->sceneUniforms.projCam, 1, 0, f->W, f->H);
 }
 
-/* Rows [y0, y1) of one frame (rect fields of the parameters ignored); all outputs host memory, full-frame
- * sized, only those rows written (the shadow map whole).  Calls for disjoint row ranges of the same frame
- * may run concurrently on the same output buffers: the scene is read-only and every call owns its
- * attachments, which is how the CPU baseline uses several cores. */
-ORA_API int ora_render_rows(const ora_scene* sc, const vkr_frame_params* fp, const vkr_frame_out* out, uint32_t y0, uint32_t y1)
+/* What ora_render_bands computes once per frame for all of its row ranges. */
+typedef struct {
+	float** clip;      /* per mesh: clip-space vertices under the camera's matrix */
+	float** clipLight; /* the same under the light's matrix (when the mode has a light pass) */
+	float* shadow;     /* the finished light depth map, or NULL when the mode has none */
+} BandShared;
+
+/* Rows [y0, y1) of one frame.  The attachments are allocated at frame size and indexed by frame position, but
+ * only the rows this call draws are cleared and touched (untouched pages of a large allocation cost nothing). */
+static int render_rows(const ora_scene* sc, const vkr_frame_params* fp, const vkr_frame_out* out, uint32_t y0, uint32_t y1,
+                       const BandShared* sh)
 {
 	init_tables();
 	Frame f;
@@ -1412,20 +1449,25 @@ ORA_API int ora_render_rows(const ora_scene* sc, const vkr_frame_params* fp, con
 	/* the mosaic pass reads the top row of each 3-row block of the image below it */
 	if (fp->mosaicEffect) { const uint32_t top = y0 - (y0 % 3u); f.sy0 = top > 4u ? top - 4u : 0u; }
 	f.S = fp->shadow_size ? fp->shadow_size : 2048;
+	f.ly0 = 0; f.ly1 = f.S;
+	if (sh) { f.sharedClip = sh->clip; f.sharedShadow = sh->shadow != NULL; f.shadow = sh->shadow; }
 	size_t n = (size_t)f.W * f.H;
 	if (n == 0) return 1;
+	const size_t r0 = (size_t)f.sy0 * f.W, r1 = (size_t)f.sy1 * f.W;
 	f.depth = (float*)malloc(n * 4); f.tri = (uint32_t*)malloc(n * 4); f.rgba = (uint8_t*)malloc(n * 4);
-	f.mip = (uint8_t*)malloc(n); f.stencil = (uint8_t*)calloc(n, 1);
+	f.mip = (uint8_t*)malloc(n); f.stencil = (uint8_t*)malloc(n);
 	f.gN = (uint16_t*)malloc(n * 8); f.gA = (uint16_t*)malloc(n * 8);
-	for (size_t i = 0; i < n; i++) { f.depth[i] = 1.0f; f.tri[i] = VKR_NO_TRIANGLE; f.mip[i] = 0xff; }
-	uint16_t h01 = float_to_half(0.1f);
-	for (size_t i = 0; i < n * 4; i++) { f.gN[i] = h01; f.gA[i] = h01; } /* clears, main/main.cpp:3843-3851 */
+	for (size_t i = r0; i < r1; i++) { f.depth[i] = 1.0f; f.tri[i] = VKR_NO_TRIANGLE; f.mip[i] = 0xff; f.stencil[i] = 0; }
 	const vkr_uniforms* u = &fp->uniforms;
 	int dbg = fp->debugVisualisation;
 	int needShadow = 0;
 
+	{
+		uint16_t h01 = float_to_half(0.1f);
+		for (size_t i = r0 * 4; i < r1 * 4; i++) { f.gN[i] = h01; f.gA[i] = h01; } /* clears, main/main.cpp:3843-3851 */
+	}
 	if (fp->deferredShading && !fp->mosaicEffect) {
-		fill_colour(f.rgba, n, 0.1f, 0.1f, 0.1f, 0.1f); /* main/main.cpp:3838-3841 */
+		fill_colour_rows(&f, 0.1f, 0.1f, 0.1f, 0.1f); /* main/main.cpp:3838-3841 */
 		f.pipe = PIPE_GBUF;
 		draw_range(&f, sc->orderA, 0, sc->nPrim, u->sceneUniforms.projCam, 1, 0, f.W, f.H);
 		deferred_light_pass(&f);
@@ -1434,26 +1476,26 @@ ORA_API int ora_render_rows(const ora_scene* sc, const vkr_frame_params* fp, con
 			 * shadow pass, main/main.cpp:3836-3946): the light's depth pass of main/main.cpp:3950-3984 is drawn as
 			 * well and handed out; the lighting does not sample it */
 			needShadow = 1;
-			f.shadow = (float*)malloc((size_t)f.S * f.S * 4);
-			for (size_t i = 0; i < (size_t)f.S * f.S; i++) f.shadow[i] = 1.0f;
-			f.pipe = PIPE_SHADOW;
-			draw_range(&f, sc->orderA, 0, sc->nPrimOpaque, u->depthMVPUniform.depthMVP, 0, 0, f.S, f.S);
+			if (!f.sharedShadow) {
+				f.shadow = (float*)malloc((size_t)f.S * f.S * 4);
+				shadow_pass(&f);
+			}
 		}
 	} else if (!fp->mosaicEffect && dbg == 1) {
 		needShadow = 1;
-		f.shadow = (float*)malloc((size_t)f.S * f.S * 4);
+		if (!f.sharedShadow) f.shadow = (float*)malloc((size_t)f.S * f.S * 4);
 		forward_passes(&f);
 	} else if (!fp->mosaicEffect && (dbg == 5 || dbg == 6)) {
 		f.pipe = PIPE_OVERVIS;
 		draw_range(&f, sc->orderB, 0, sc->nPrim, u->sceneUniforms.projCam, 1, 1, f.W, f.H);
 		/* overVisRead.frag:7-13 */
-		for (size_t p = 0; p < n; p++) {
+		for (size_t p = r0; p < r1; p++) {
 			float s = (float)f.stencil[p] / 25.0f;
 			float c[4] = { 0.0f + s, 0.3f + s, 0.0f + s, 0.1f + 0.0f };
 			write_colour(f.rgba + p * 4, c);
 		}
 	} else if (!fp->mosaicEffect) {
-		fill_colour(f.rgba, n, 0.1f, 0.1f, 0.1f, 1.0f); /* main/main.cpp:4139-4143 */
+		fill_colour_rows(&f, 0.1f, 0.1f, 0.1f, 1.0f); /* main/main.cpp:4139-4143 */
 		f.pipe = PIPE_DEBUG;
 		draw_range(&f, sc->orderB, 0, sc->nPrim, u->sceneUniforms.projCam, 1, 1, f.W, f.H);
 	} else {
@@ -1463,10 +1505,10 @@ ORA_API int ora_render_rows(const ora_scene* sc, const vkr_frame_params* fp, con
 		 * shadow term undefined; this restatement renders the shadow map as the
 		 * regular path does. */
 		needShadow = 1;
-		f.shadow = (float*)malloc((size_t)f.S * f.S * 4);
+		if (!f.sharedShadow) f.shadow = (float*)malloc((size_t)f.S * f.S * 4);
 		forward_passes(&f);
 		uint8_t* dst = (uint8_t*)malloc(n * 4);
-		mosaic_pass(f.rgba, dst, f.W, f.H);
+		mosaic_pass(f.rgba, dst, f.W, f.H, y0, y1);
 		free(f.rgba);
 		f.rgba = dst;
 	}
@@ -1481,24 +1523,75 @@ ORA_API int ora_render_rows(const ora_scene* sc, const vkr_frame_params* fp, con
 		if (out->gbuf_normal) memcpy(out->gbuf_normal + o * 4, f.gN + o * 4, m * 8);
 		if (out->gbuf_albedo) memcpy(out->gbuf_albedo + o * 4, f.gA + o * 4, m * 8);
 	}
-	if (out->shadow_map && needShadow) memcpy(out->shadow_map, f.shadow, (size_t)f.S * f.S * 4);
-	free(f.depth); free(f.tri); free(f.rgba); free(f.mip); free(f.stencil); free(f.gN); free(f.gA); free(f.shadow);
+	if (!f.sharedShadow) {
+		if (out->shadow_map && needShadow) memcpy(out->shadow_map, f.shadow, (size_t)f.S * f.S * 4);
+		free(f.shadow);
+	}
+	free(f.depth); free(f.tri); free(f.rgba); free(f.mip); free(f.stencil); free(f.gN); free(f.gA);
 	return 0;
 }
 
-/* One whole frame as bands of band_rows rows.  Compiled with -fopenmp (the timing build of the CPU baseline) the bands
- * are rendered by an OpenMP team, dynamically scheduled: the cost of a band depends on what it shows.  Without OpenMP the
- * pragma is ignored and the bands are rendered one after the other.  Same frame either way. */
+/* Rows [y0, y1) of one frame (rect fields of the parameters ignored); all outputs host memory, full-frame
+ * sized, only those rows written (the shadow map whole).  Calls for disjoint row ranges of the same frame
+ * may run concurrently on the same output buffers as long as no shadow map is asked for (every call would
+ * write the whole map): the scene is read-only and every call owns its attachments. */
+ORA_API int ora_render_rows(const ora_scene* sc, const vkr_frame_params* fp, const vkr_frame_out* out, uint32_t y0, uint32_t y1)
+{
+	return render_rows(sc, fp, out, y0, y1, NULL);
+}
+
+/* One whole frame as bands of band_rows rows, the way a CPU renderer with several cores would draw it: the vertices
+ * are transformed once, the light's depth map is drawn once (as bands of its own rows) and then only read, and every
+ * band clears, draws and shades its own rows only.  Compiled with -fopenmp the three steps are shared by an OpenMP
+ * team, dynamically scheduled (the cost of a band depends on what it shows); without OpenMP the pragmas are ignored
+ * and everything runs in turn.  Same frame either way, and the same as ora_render's. */
 ORA_API int ora_render_bands(const ora_scene* sc, const vkr_frame_params* fp, const vkr_frame_out* out, uint32_t band_rows)
 {
 	if (!band_rows) band_rows = 64;
+	init_tables();
+	const uint32_t S = fp->shadow_size ? fp->shadow_size : 2048;
+	const int dbg = fp->debugVisualisation;
+	const int deferred = fp->deferredShading && !fp->mosaicEffect;
+	const int shadowed = deferred ? ((fp->flags & VKR_FRAME_SHADOW_PASS) && out->shadow_map) : (fp->mosaicEffect || dbg == 1);
+	BandShared sh;
+	sh.clip = (float**)calloc(sc->nMesh ? sc->nMesh : 1, sizeof(float*));
+	sh.shadow = shadowed ? (float*)malloc((size_t)S * S * 4) : NULL;
+	sh.clipLight = (float**)calloc(sc->nMesh ? sc->nMesh : 1, sizeof(float*));
+	for (uint32_t mi = 0; mi < sc->nMesh; mi++) {
+		const size_t nv = sc->mesh[mi].V ? sc->mesh[mi].V : 1;
+		sh.clip[mi] = (float*)malloc(sizeof(float) * 4 * nv);
+		if (shadowed && !sc->mesh[mi].alpha) sh.clipLight[mi] = (float*)malloc(sizeof(float) * 4 * nv);
+	}
+	/* the vertex stage, once per frame and pass */
+#pragma omp parallel for schedule(dynamic, 1)
+	for (int mi = 0; mi < (int)sc->nMesh; mi++) {
+		const OraMesh* m = &sc->mesh[mi];
+		for (uint32_t v = 0; v < m->V; v++) xform(fp->uniforms.sceneUniforms.projCam, m->pos + 3 * (size_t)v, sh.clip[mi] + 4 * (size_t)v);
+		if (sh.clipLight[mi])
+			for (uint32_t v = 0; v < m->V; v++) xform(fp->uniforms.depthMVPUniform.depthMVP, m->pos + 3 * (size_t)v, sh.clipLight[mi] + 4 * (size_t)v);
+	}
+	if (shadowed) {
+		const int nl = (int)((S + 63u) / 64u);
+#pragma omp parallel for schedule(dynamic, 1)
+		for (int b = 0; b < nl; b++) {
+			Frame f;
+			memset(&f, 0, sizeof f);
+			f.sc = sc; f.fp = fp; f.W = fp->width; f.H = fp->height; f.S = S; f.shadow = sh.shadow;
+			f.sharedClipLight = sh.clipLight;
+			f.ly0 = (uint32_t)b * 64u; f.ly1 = f.ly0 + 64u < S ? f.ly0 + 64u : S;
+			shadow_pass(&f);
+		}
+	}
 	const int nb = (int)((fp->height + band_rows - 1) / band_rows);
 	int bad = 0;
 #pragma omp parallel for schedule(dynamic, 1) reduction(| : bad)
 	for (int b = 0; b < nb; b++) {
 		const uint32_t y0 = (uint32_t)b * band_rows, y1 = y0 + band_rows;
-		bad |= ora_render_rows(sc, fp, out, y0, y1 < fp->height ? y1 : fp->height);
+		bad |= render_rows(sc, fp, out, y0, y1 < fp->height ? y1 : fp->height, &sh);
 	}
+	if (sh.shadow && out->shadow_map) memcpy(out->shadow_map, sh.shadow, (size_t)S * S * 4);
+	for (uint32_t mi = 0; mi < sc->nMesh; mi++) { free(sh.clip[mi]); free(sh.clipLight[mi]); }
+	free(sh.clip); free(sh.clipLight); free(sh.shadow);
 	return bad;
 }
 
