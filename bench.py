@@ -186,8 +186,11 @@ def cpu_baseline(packed, params_for, W, H, mode_name, scene, np):
         L.ora_set_band_threads.argtypes = [C.c_int]
         h = L.ora_scene_create(C.byref(packed.desc))
         img = np.zeros((H, W, 4), np.uint8)
+        ref_tri, ref_depth = np.zeros((H, W), np.uint32), np.zeros((H, W), np.uint32)
         fo = abi.FrameOut()
         fo.rgba8 = img.ctypes.data
+        fo.tri_id = ref_tri.ctypes.data
+        fo.depth_bits = ref_depth.ctypes.data
         if p.flags & abi.FRAME_SHADOW_PASS:  # the composition with a light depth pass: the CPU draws that pass as well
             S = p.shadow_size or 2048
             smap = np.zeros((S, S), np.float32)
@@ -205,27 +208,31 @@ def cpu_baseline(packed, params_for, W, H, mode_name, scene, np):
             times = sorted(times[1:])  # the first frame is the warm-up
             res[threads] = times[len(times) // 2]
         L.ora_scene_destroy(h)
-        ref = img
+        ref = {"rgba8": img, "tri_id": ref_tri, "depth_bits": ref_depth}
         build = "-O3 -march=native -fopenmp, built on this machine"
     else:
         # no compiler here: the -O2 checker build, bands over a Python thread pool
         threads = min(16, usable)
         osc = oracle.OracleScene(packed)
         t0 = time.perf_counter()
-        ref = osc.render(p, want=("rgba8",), threads=threads)["rgba8"]
+        ref = osc.render(p, want=("rgba8", "tri_id", "depth_bits"), threads=threads)
         res[threads] = time.perf_counter() - t0
         osc.close()
         build = "-O2 (no compiler on this machine for the timing build), one frame"
     top = max(res)
     # the oracle frame doubles as a check of the frame the GPU path produces for the same pose
-    got = scene.render(params_for(0, renderer.make_uniforms), want=("rgba8",))["rgba8"]
-    diff = np.abs(ref.astype(np.int32) - got.astype(np.int32))
+    got = scene.render(params_for(0, renderer.make_uniforms), want=("rgba8", "tri_id", "depth_bits"))
+    diff = np.abs(ref["rgba8"].astype(np.int32) - got["rgba8"].astype(np.int32))
     mse = float(np.mean(diff.astype(np.float64) ** 2))
+    # the integer buffers must be the oracle's bit for bit
+    ints = {"tri_id_mismatches": int((ref["tri_id"] != got["tri_id"]).sum()),
+            "depth_bits_mismatches": int((ref["depth_bits"] != got["depth_bits"]).sum())}
     out = {"value": round(W * H / res[top] / 1e6, 4), "unit": "Mpix/s", "cores": top, "kind": "port",
            "sample": "pose 0 of the same workload (%dx%d %s) by the CPU restatement oracle/vkr_oracle.c (%s), OpenMP over bands of rows, "
                      "1 warm-up + 5 timed frames, median %.2f s per frame" % (W, H, mode_name, build, res[top]),
            "host_physical_cores": phys, "host_usable_cpus": usable,
-           "gpu_frame_vs_oracle": {"max_abs_diff_8bit": int(diff.max()), "psnr_db": (99.0 if mse == 0 else round(10 * math.log10(255.0 ** 2 / mse), 1))}}
+           "gpu_frame_vs_oracle": dict({"max_abs_diff_8bit": int(diff.max()),
+                                        "psnr_db": (99.0 if mse == 0 else round(10 * math.log10(255.0 ** 2 / mse), 1))}, **ints)}
     for t, dt in res.items():
         if t != top:
             out["value_at_%d_threads" % t] = round(W * H / dt / 1e6, 4)

@@ -34,6 +34,7 @@ def test_one_rank_line_follows_the_contract():
     assert r["algorithmic_bytes_per_launch"] == 24 * 640 * 352
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["gpu_frame_vs_oracle"]["max_abs_diff_8bit"] <= 1
+    assert c["gpu_frame_vs_oracle"]["tri_id_mismatches"] == 0 and c["gpu_frame_vs_oracle"]["depth_bits_mismatches"] == 0
     assert d["fast_path"]["value"] > 0 and "workload" in d["config"]
 
 

@@ -9,6 +9,14 @@ __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsq
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float sat(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 
+// n / d from the hardware reciprocal r ~ 1/d and one residual correction: the rounded quotient (but for rare ties)
+__device__ __forceinline__ float vkr_div_fix(float n, float d, float r)
+{
+	const float q = n * r;
+	return __builtin_fmaf(__builtin_fmaf(-q, d, n), r, q);
+}
+__device__ __forceinline__ float vkr_div_rn(float n, float d) { return vkr_div_fix(n, d, fast_rcp(d)); }
+
 __device__ __forceinline__ float h2f_lo(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)); }
 __device__ __forceinline__ float h2f_hi(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); }
 
@@ -20,15 +28,26 @@ __device__ __forceinline__ uint32_t vkr_light_pixel(const LightArgs& a, const fl
 {
 #pragma clang fp contract(fast)
 	const float px = (float)(a.view.x0 + x), py = (float)vkr_view_gy(a.view, y);
-	// posFromDepth: clip = (uv*2-1, depth, 1); world = (inverse(camera)*inverse(projection)) * clip
-	const float cx = ((px + 0.5f) * fast_rcp((float)a.view.W)) * 2.0f - 1.0f;
-	const float cy = ((py + 0.5f) * fast_rcp((float)a.view.H)) * 2.0f - 1.0f;
-	float vs[4];
+	// posFromDepth: clip = (uv*2-1, depth, 1); world = (inverse(camera)*inverse(projection)) * clip.
+	// The position is the one ill-conditioned input of the pass: w = m23*depth + m33 cancels to ~1/100 of its terms at
+	// far depths, and next to a brazier N.L is a difference of positions.  Every operation up to the position is
+	// therefore written out in one fixed order (product rounded, then fused adds, as the CPU restatement does) instead
+	// of being left to the compiler's contraction, and the quotients are corrected to the rounded result.
+	float vs[4], Px, Py, Pz;
+	{
+#pragma clang fp contract(off)
+		const float cx = vkr_div_rn(px + 0.5f, (float)a.view.W) * 2.0f - 1.0f;
+		const float cy = vkr_div_rn(py + 0.5f, (float)a.view.H) * 2.0f - 1.0f;
 #pragma unroll
-	for (int i = 0; i < 4; i++)
-		vs[i] = a.invPC.m[0 * 4 + i] * cx + a.invPC.m[1 * 4 + i] * cy + a.invPC.m[2 * 4 + i] * depth + a.invPC.m[3 * 4 + i];
-	const float iw = fast_rcp(vs[3]);
-	const float Px = vs[0] * iw, Py = vs[1] * iw, Pz = vs[2] * iw;
+		for (int i = 0; i < 4; i++) {
+			float t = a.invPC.m[0 * 4 + i] * cx;
+			t = __builtin_fmaf(a.invPC.m[1 * 4 + i], cy, t);
+			t = __builtin_fmaf(a.invPC.m[2 * 4 + i], depth, t);
+			vs[i] = t + a.invPC.m[3 * 4 + i];
+		}
+		const float iw = fast_rcp(vs[3]);
+		Px = vkr_div_fix(vs[0], vs[3], iw); Py = vkr_div_fix(vs[1], vs[3], iw); Pz = vkr_div_fix(vs[2], vs[3], iw);
+	}
 	float Vx = a.camPos[0] - Px, Vy = a.camPos[1] - Py, Vz = a.camPos[2] - Pz;
 	{
 		float inv = fast_rsq(Vx * Vx + Vy * Vy + Vz * Vz);
