@@ -11,6 +11,7 @@
 //        ref_fixtures tangents            -> JSON on stdout
 //        ref_fixtures loadmodel <file>    -> JSON on stdout
 //        ref_fixtures stb <png>...        -> JSON on stdout (stbi_load(...,4) flipped, as utils/vkimage.cpp:62-65)
+//        ref_fixtures stbsha <png>...     -> the same for large files: size, channel count and SHA-256 of the decoded RGBA8
 //        ref_fixtures userstate           -> JSON on stdout (camera2world after each step of an input trace)
 #include <cstdint>
 #include <cstdio>
@@ -172,6 +173,66 @@ static int do_loadmodel(const char* path)
 	return 0;
 }
 
+// SHA-256 (FIPS 180-4) of a byte buffer, as 64 hex digits
+static void sha256_hex(const unsigned char* data, std::size_t len, char out[65])
+{
+	static const std::uint32_t K[64] = {
+		0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+		0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+		0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+		0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+		0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+		0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2 };
+	std::uint32_t h[8] = { 0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19 };
+	auto rotr = [](std::uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+	auto block = [&](const unsigned char* p) {
+		std::uint32_t w[64];
+		for (int i = 0; i < 16; i++) w[i] = (std::uint32_t(p[4 * i]) << 24) | (std::uint32_t(p[4 * i + 1]) << 16) | (std::uint32_t(p[4 * i + 2]) << 8) | p[4 * i + 3];
+		for (int i = 16; i < 64; i++) {
+			const std::uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+			w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+		}
+		std::uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+		for (int i = 0; i < 64; i++) {
+			const std::uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+			const std::uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+			hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+		}
+		h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+	};
+	std::size_t i = 0;
+	for (; i + 64 <= len; i += 64) block(data + i);
+	unsigned char tail[128] = { 0 };
+	const std::size_t rest = len - i;
+	std::memcpy(tail, data + i, rest);
+	tail[rest] = 0x80;
+	const std::size_t padded = rest + 9 <= 64 ? 64 : 128;
+	const unsigned long long bits = (unsigned long long)len * 8;
+	for (int k = 0; k < 8; k++) tail[padded - 1 - k] = (unsigned char)(bits >> (8 * k));
+	block(tail);
+	if (padded == 128) block(tail + 64);
+	for (int k = 0; k < 8; k++) std::snprintf(out + 8 * k, 9, "%08x", h[k]);
+}
+
+static int do_stbsha(int n, char** files)
+{
+	stbi_set_flip_vertically_on_load(1);
+	std::printf("{\n");
+	for (int i = 0; i < n; i++) {
+		int w = 0, h = 0, c = 0;
+		stbi_uc* data = stbi_load(files[i], &w, &h, &c, 4);
+		const char* base = std::strrchr(files[i], '/');
+		base = base ? base + 1 : files[i];
+		if (!data) { std::printf("  \"%s\": null%s\n", base, i + 1 == n ? "" : ","); continue; }
+		char hex[65];
+		sha256_hex(data, (std::size_t)w * h * 4, hex);
+		std::printf("  \"%s\": {\"width\": %d, \"height\": %d, \"file_channels\": %d, \"sha256\": \"%s\"}%s\n", base, w, h, c, hex, i + 1 == n ? "" : ",");
+		stbi_image_free(data);
+	}
+	std::printf("}\n");
+	return 0;
+}
+
 static int do_stb(int n, char** files)
 {
 	stbi_set_flip_vertically_on_load(1);
@@ -264,7 +325,8 @@ try {
 	if (argc >= 2 && 0 == std::strcmp(argv[1], "userstate")) return do_userstate();
 	if (argc >= 3 && 0 == std::strcmp(argv[1], "loadmodel")) return do_loadmodel(argv[2]);
 	if (argc >= 3 && 0 == std::strcmp(argv[1], "stb")) return do_stb(argc - 2, argv + 2);
-	std::fprintf(stderr, "usage: ref_fixtures matrices|tangents|userstate|loadmodel <file>|stb <png>...\n");
+	if (argc >= 3 && 0 == std::strcmp(argv[1], "stbsha")) return do_stbsha(argc - 2, argv + 2);
+	std::fprintf(stderr, "usage: ref_fixtures matrices|tangents|userstate|loadmodel <file>|stb <png>...|stbsha <png>...\n");
 	return 2;
 } catch (std::exception const& e) {
 	std::fprintf(stderr, "error: %s\n", e.what());

@@ -199,3 +199,44 @@ def test_bake_errors(tmp_path):
     p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")   # no vt / vn / material
     with pytest.raises(bake.BakeError):
         bake.bake_obj(str(p), str(tmp_path / "o.comp5892mesh"))
+
+
+REAL_MTL = os.path.join(os.environ.get("VKR_REFERENCE_ASSETS", "/root/reference/assets-src/main"), "suntemple.mtl")
+
+
+@pytest.mark.skipif(not os.path.exists(REAL_MTL), reason="the reference's material library exists in the build container only")
+def test_real_material_library_bakes_like_the_reference_tool(tmp_path):
+    """The real suntemple.mtl (48 materials) under one triangle per material (tests/golden/bake/mtl_materials.obj): the
+    library writes the bytes the reference's own bake tool wrote for it (tests/make_asset_fixtures.py) - material order,
+    the unique-texture table in its unordered_map order, colour spaces and channel counts, the fall-back textures of
+    materials without maps (main-bake/main.cpp:236-251, 426-457) - and the alpha mask sits on exactly the three
+    materials that carry a map_d line (the ones that start at suntemple.mtl:131, 330, 349; main/main.cpp:1080-1081)."""
+    from vulkanrenderer_amd import bake, baked_model
+    src = tmp_path / "assets-src" / "main"
+    src.mkdir(parents=True)
+    shutil.copy(os.path.join(GOLD, "bake", "mtl_materials.obj"), str(src / "suntemple.obj-zstd"))
+    os.symlink(REAL_MTL, str(src / "suntemple.mtl"))
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        bake.bake_obj("assets-src/main/suntemple.obj-zstd", "assets/main/suntemple.comp5892mesh")
+    finally:
+        os.chdir(cwd)
+    out = tmp_path / "assets" / "main" / "suntemple.comp5892mesh"
+    assert out.read_bytes() == open(os.path.join(GOLD, "bake", "ref_suntemple_mtl.comp5892mesh"), "rb").read()
+    tex, mats, meshes, trailing = baked_model.read_baked_model(str(out))
+    assert trailing == 0 and len(mats) == 48 and len(meshes) == 48
+    # the materials with a map_d line, by their position in the library
+    names, masked, lines, started = [], [], [], 0
+    for no, line in enumerate(open(REAL_MTL), 1):
+        if line.startswith("newmtl"):
+            names.append(line.split(None, 1)[1].strip()); started = no
+        elif line.split()[:1] == ["map_d"]:
+            masked.append(len(names) - 1); lines.append(started)
+    assert lines == [131, 330, 349] and len(names) == 48   # the three double-sided foliage materials
+    # the material table keeps the library's order; mesh k is the triangle drawn with material k
+    with_mask = [i for i, m in enumerate(mats) if m[3] != 0xFFFFFFFF]
+    assert with_mask == masked
+    assert sorted(m["materialId"] for m in meshes) == list(range(48))
+    # 193 scene textures + the fall-backs in use; the reader prefixes the file's directory to the stored names
+    assert 190 <= len(tex) <= 196 and all("/suntemple-tex/" in t[0] for t in tex)
