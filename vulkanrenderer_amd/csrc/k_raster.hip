@@ -127,6 +127,21 @@ extern "C" __attribute__((visibility("default"))) int vkr_debug_wg_times(int mod
 #define WG_T(k)
 #endif
 
+#ifdef VKR_RASTER_STATS
+// measurement build only (make EXTRA=-DVKR_RASTER_STATS): what the opaque camera pass walks.  [0] sub-triangles taken one
+// per lane group, [1] pixels of their boxes, [2] sub-triangles taken by a whole wavefront, [3] pixels of their boxes,
+// [4] 8x8 block steps spent on them, [5] steps a row-major walk of the same boxes would take
+__device__ unsigned long long g_rstats[8];
+extern "C" __attribute__((visibility("default"))) int vkr_debug_raster_stats(void* dst, int clear)
+{
+	if (clear) { static unsigned long long z[8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rstats), z, sizeof z); }
+	return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rstats), sizeof(g_rstats), 0, hipMemcpyDeviceToHost);
+}
+#define RS_ADD(k, v) atomicAdd(&g_rstats[k], (unsigned long long)(v))
+#else
+#define RS_ADD(k, v)
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 {
@@ -191,6 +206,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 		const int area = nonEmpty ? (bx1 - bx0 + 1) * (by1 - by0 + 1) : 0;
 		const bool big = nonEmpty && area > BIG_AREA;
 
+		if (MODE == RASTER_VIS && sub == 0 && nonEmpty && !big) { RS_ADD(0, 1); RS_ADD(1, area); }
 		if (nonEmpty && !big) {
 			EdgeSetup E;
 			edge_setup(s, bx0 + (int)sub, by0, E);
@@ -215,6 +231,10 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 			int wx0, wy0, wx1, wy1;
 			bcast_subtri(s, bx0, by0, bx1, by1, src, w, wx0, wy0, wx1, wy1);
 			const int lx = (int)(lane & 7), ly = (int)(lane >> 3);
+			if (MODE == RASTER_VIS && lane == 0) {
+				RS_ADD(2, 1); RS_ADD(3, (wx1 - wx0 + 1) * (wy1 - wy0 + 1)); RS_ADD(4, (((wx1 - wx0) >> 3) + 1) * (((wy1 - wy0) >> 3) + 1));
+				RS_ADD(5, ((wx1 - wx0 + 1) * (wy1 - wy0 + 1) + 63) / 64);
+			}
 			// edge values at this lane's pixel of the first 8x8 block, then stepped block by block
 			EdgeSetup E;
 			edge_setup(w, wx0 + lx, wy0 + ly, E);
