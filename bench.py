@@ -62,12 +62,26 @@ def fly_pose(i, n=512):
     return [c, 0.0, -s, 0.0, 0.0, 1.0, 0.0, 0.0, s, 0.0, c, 0.0, 0.0, -1.0, tz, 1.0]
 
 
+# what each profiled kernel is compiled from: a committed counter summary describes the kernel only while these files are
+# the ones it was taken on
+PROFILED_SOURCES = {"k_deferred_light": ("k_light.hip", "vkr_light.h", "vkr_device.h", "vkr_kernels.h")}
+
+
+def source_sha256(name):
+    import hashlib
+    with open(os.path.join(ROOT, "vulkanrenderer_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def newest_profile(pattern, width, height, kernel, key):
-    """Value `key` of `kernel` from the newest committed PMC summary (profiles/<pattern>) taken at this extent, or None.
-    PMC counters need their own rocprofv3 passes, so they cannot be collected inside this run."""
+    """(value, file, git commit, stale) of `key` for `kernel` from the committed PMC summary (profiles/<pattern>) taken
+    last at this extent - by the time recorded inside the file, not by its name - or None.  PMC counters need their own
+    rocprofv3 passes, so they cannot be collected inside this run; `stale` says the kernel's sources have changed since
+    the passes ran (hashes recorded in the summary against the files of this tree; a summary without hashes cannot
+    vouch for anything), and the caller then reports no number."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
+    for path in glob.glob(os.path.join(ROOT, "profiles", pattern)):
         try:
             with open(path) as f:
                 j = json.load(f)
@@ -75,10 +89,19 @@ def newest_profile(pattern, width, height, kernel, key):
             continue
         if j.get("width") != width or j.get("height") != height:
             continue
+        taken = j.get("taken_unix", 0)
         for name, k in j.get("kernels", {}).items():
-            if name.startswith(kernel) and key in k:
-                best = (k[key], os.path.basename(path))
-    return best
+            if name.startswith(kernel) and key in k and (best is None or (taken, path) > best[0]):
+                best = ((taken, path), k[key], j)
+    if best is None:
+        return None
+    (_, path), value, j = best
+    recorded = j.get("source_sha256") or {}
+    try:
+        stale = not recorded or any(recorded.get(n) != source_sha256(n) for n in PROFILED_SOURCES.get(kernel, ()))
+    except OSError:
+        stale = True
+    return value, os.path.basename(path), j.get("git_commit"), stale
 
 
 def parse_args(argv=None):
@@ -389,17 +412,20 @@ def run(args):
         launch_pixels = W * my_rows
         achieved = LIGHT_BYTES_PER_PIXEL * launch_pixels / (avg_ms * 1e-3) / 1e9
         traffic = newest_profile("*pmc_traffic*.json", W, my_rows, "k_deferred_light", "hbm_bytes_per_launch_corrected") if args.mode == "deferred" else None
+        fresh = traffic is not None and not traffic[3]
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(traffic[0]) if traffic else None,
-                    "traffic_source": ("profiles/" + traffic[1]) if traffic else None, "kernel": "k_deferred_light",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(traffic[0]) if fresh else None,
+                    "traffic_source": ("profiles/%s (commit %s)" % (traffic[1], traffic[2] or "unrecorded")) if fresh else
+                                      ("none: profiles/%s was taken on other kernel sources" % traffic[1]) if traffic else None,
+                    "kernel": "k_deferred_light",
                     "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": LIGHT_BYTES_PER_PIXEL * launch_pixels,
                     # the fraction is measured against the HBM roofline, which is the graded number; what actually limits the
                     # kernel is vector-ALU issue (21 BRDF evaluations per pixel), see valu_issue_frac
                     "limited_by": "valu-issue"}
         issue = newest_profile("*pmc_valu*.json", W, my_rows, "k_deferred_light", "valu_issue_frac") if args.mode == "deferred" else None
-        if issue:
+        if issue and not issue[3]:
             roofline["valu_issue_frac"] = round(float(issue[0]), 4)  # VALU instructions x 2 cycles / (SIMDs x kernel cycles), not clamped
-            roofline["valu_issue_source"] = "profiles/" + issue[1]
+            roofline["valu_issue_source"] = "profiles/%s (commit %s)" % (issue[1], issue[2] or "unrecorded")
 
     # The same workload the fastest way the library renders it - resolve and lighting as one kernel, two frames in
     # flight - timed in this run as well, beside the headline composition (which keeps the graded lighting kernel a

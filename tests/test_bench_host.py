@@ -77,20 +77,41 @@ def test_a_failing_rank_fails_the_launch(monkeypatch):
 
 
 def test_newest_counter_summary_of_the_right_extent(tmp_path, monkeypatch):
+    """The summary is picked by the time recorded inside it, never by its file name, and only vouches for the kernel
+    while the recorded source hashes are those of the tree."""
     prof = tmp_path / "profiles"
     prof.mkdir()
-    for name, w, h, v in (("r01_pmc_traffic_4k.json", 3840, 2160, 1.0), ("r02_pmc_traffic_4k.json", 3840, 2160, 2.0),
-                          ("r03_pmc_traffic_1080.json", 1920, 1080, 3.0)):
-        (prof / name).write_text(json.dumps({"width": w, "height": h, "kernels": {"k_deferred_light<true>": {"x": v}, "k_other": {"x": 9.0}}}))
-    (prof / "r04_pmc_traffic_4k.json").write_text("not json")
+    src = tmp_path / "vulkanrenderer_amd" / "csrc"
+    src.mkdir(parents=True)
+    for n in bench.PROFILED_SOURCES["k_deferred_light"]:
+        (src / n).write_text("// " + n)
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    assert bench.newest_profile("*pmc_traffic*.json", 3840, 2160, "k_deferred_light", "x") == (2.0, "r02_pmc_traffic_4k.json")
-    assert bench.newest_profile("*pmc_traffic*.json", 1920, 1080, "k_deferred_light", "x") == (3.0, "r03_pmc_traffic_1080.json")
-    assert bench.newest_profile("*pmc_traffic*.json", 1280, 720, "k_deferred_light", "x") is None
+    now = {n: bench.source_sha256(n) for n in bench.PROFILED_SOURCES["k_deferred_light"]}
+    old = dict(now, **{"k_light.hip": "0" * 64})
+    # zz_ sorts last by name but was taken first; the one taken last carries the hashes of the tree
+    for name, w, h, v, taken, hashes, commit in (
+            ("zz_pmc_traffic_4k.json", 3840, 2160, 1.0, 100, old, "aaaaaaa"), ("r02_pmc_traffic_4k.json", 3840, 2160, 2.0, 300, now, "bbbbbbb"),
+            ("r01_pmc_traffic_4k.json", 3840, 2160, 4.0, 200, now, None), ("r03_pmc_traffic_1080.json", 1920, 1080, 3.0, 50, old, "ccccccc"),
+            ("r00_pmc_traffic_720.json", 1280, 720, 5.0, None, None, None)):
+        j = {"width": w, "height": h, "kernels": {"k_deferred_light<true>": {"x": v}, "k_other": {"x": 9.0}}}
+        if taken is not None:
+            j.update(taken_unix=taken, source_sha256=hashes, git_commit=commit)
+        (prof / name).write_text(json.dumps(j))
+    (prof / "r04_pmc_traffic_4k.json").write_text("not json")
+    assert bench.newest_profile("*pmc_traffic*.json", 3840, 2160, "k_deferred_light", "x") == (2.0, "r02_pmc_traffic_4k.json", "bbbbbbb", False)
+    # taken on other sources: found, but stale
+    assert bench.newest_profile("*pmc_traffic*.json", 1920, 1080, "k_deferred_light", "x") == (3.0, "r03_pmc_traffic_1080.json", "ccccccc", True)
+    # a summary that records no hashes vouches for nothing
+    assert bench.newest_profile("*pmc_traffic*.json", 1280, 720, "k_deferred_light", "x") == (5.0, "r00_pmc_traffic_720.json", None, True)
+    assert bench.newest_profile("*pmc_traffic*.json", 640, 360, "k_deferred_light", "x") is None
+    # a change of the kernel's source turns the newest summary stale
+    (src / "vkr_light.h").write_text("// edited")
+    assert bench.newest_profile("*pmc_traffic*.json", 3840, 2160, "k_deferred_light", "x")[3] is True
 
 
 def test_committed_profiles_feed_the_bench_line():
-    """The counter summaries the default line quotes exist for its extent and carry the keys it reads."""
+    """The counter summaries the default line quotes exist for its extent and carry the keys it reads; when they are
+    current (taken on the lighting kernel's sources as they are in this tree) the traffic is the algorithmic figure."""
     t = bench.newest_profile("*pmc_traffic*.json", 3840, 2160, "k_deferred_light", "hbm_bytes_per_launch_corrected")
     v = bench.newest_profile("*pmc_valu*.json", 3840, 2160, "k_deferred_light", "valu_issue_frac")
     assert t and abs(t[0] / (24 * 3840 * 2160) - 1.0) < 0.01   # no wasted re-reads: within 1 % of the algorithmic bytes

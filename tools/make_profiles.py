@@ -10,7 +10,25 @@ Every DIR is the -d directory of one pass over `python3 tools/stage_times.py --p
   --valu    --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM
   --valu2   --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 TA_TA_BUSY_sum
 """
-import argparse, collections, csv, glob, json, os
+import argparse, collections, csv, glob, hashlib, json, os, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the files each summarised kernel is compiled from: bench.py quotes a summary only while these still hash the same
+KERNEL_SOURCES = ("k_geometry.hip", "k_raster.hip", "k_resolve.hip", "k_light.hip", "k_texture.hip", "vkr_light.h", "vkr_device.h", "vkr_kernels.h")
+
+
+def source_hashes():
+    out = {}
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "vulkanrenderer_amd", "csrc", name), "rb") as f:
+            out[name] = hashlib.sha256(f.read()).hexdigest()
+    return out
+
+
+def stamp(tag, commit):
+    """What identifies a summary: when it was taken, on which sources (content hashes; the GPU box holds no git
+    history, so the commit is whatever the caller passes in)."""
+    return {"tag": tag, "taken_unix": int(time.time()), "git_commit": commit or None, "source_sha256": source_hashes()}
 
 
 def per_kernel(d):
@@ -32,6 +50,7 @@ def avg(x):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
+    ap.add_argument("--commit", default=os.environ.get("VKR_COMMIT", ""), help="git commit of the tree the passes ran on (the GPU box has no .git)")
     ap.add_argument("--out", default="gpurun_out")
     ap.add_argument("--fetch"); ap.add_argument("--write"); ap.add_argument("--valu"); ap.add_argument("--valu2")
     ap.add_argument("--width", type=int, default=3840); ap.add_argument("--height", type=int, default=2160)
@@ -45,7 +64,7 @@ def main():
             w = wr.get(k, {}).get("WRITE_SIZE", [])
             ks[k] = {"FETCH_SIZE_KB_avg": round(avg(f), 1), "launches_FETCH_SIZE": len(f), "WRITE_SIZE_KB_avg": round(avg(w), 1),
                      "launches_WRITE_SIZE": len(w), "hbm_bytes_per_launch_corrected": int(round((2 * avg(f) + avg(w)) * 1024))}
-        json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 tools/stage_times.py --poses 0 --reps 3 --tex-size 1024",
+        json.dump({**stamp(a.tag, a.commit), "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 tools/stage_times.py --poses 0 --reps 3 --tex-size 1024",
                    "workload": a.workload, "width": a.width, "height": a.height,
                    "note": "FETCH_SIZE and WRITE_SIZE are in KB; FETCH_SIZE on gfx950 tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section), hence the doubling",
                    "kernels": ks}, open(os.path.join(a.out, a.tag + "_pmc_traffic_4k.json"), "w"), indent=1)
@@ -72,7 +91,7 @@ def main():
             if "TA_TA_BUSY_sum" in c2:
                 e["ta_busy_frac"] = round(avg(c2["TA_TA_BUSY_sum"]) / (256.0 * cyc), 3)
             ks[k] = e
-        json.dump({"command": "two passes: rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM and --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 TA_TA_BUSY_sum, each with --output-format csv -- python3 tools/stage_times.py --poses 0 --reps 2 --tex-size 1024",
+        json.dump({**stamp(a.tag, a.commit), "command": "two passes: rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM and --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 TA_TA_BUSY_sum, each with --output-format csv -- python3 tools/stage_times.py --poses 0 --reps 2 --tex-size 1024",
                    "workload": a.workload, "width": a.width, "height": a.height,
                    "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); SQ_ACTIVE_INST_* count quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_ACTIVE_INST_VALU sums the cycles each wave spends in a vector instruction, and two waves of a SIMD overlap there, so it can exceed 1 without the ALU being saturated; valu_issue_frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles) is the share of issue slots used. ta_busy_frac = TA_TA_BUSY_sum / (256 texture-address units x kernel cycles)",
                    "kernels": ks}, open(os.path.join(a.out, a.tag + "_pmc_valu_4k.json"), "w"), indent=1)
