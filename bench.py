@@ -312,9 +312,12 @@ def run(args):
     if sortfirst and args.mode == "mosaic" and stripe_h:
         raise SystemExit("bench.py: the mosaic pass is not rendered in stripes; use bands")
     comp, rect, stripes = None, None, 0
+    # frames in flight; the RCCL compositor queues a frame's exchange on the frame's own lane, so sort-first keeps its
+    # lanes (the host-tensor rehearsal waits for every frame and has one)
+    lanes = 1 if (sortfirst and args.backend != "nccl") else max(1, args.lanes)
     if sortfirst:
         if args.backend == "nccl":
-            comp = RcclCompositor(ctx, W, H, rank, world, dev, stripe_height=stripe_h)
+            comp = RcclCompositor(ctx, W, H, rank, world, dev, stripe_height=stripe_h, lanes=lanes)
         else:
             comp = HostCompositor(W, H, dev, rank, world, stripe_height=stripe_h)
         out_t = comp.local
@@ -327,10 +330,12 @@ def run(args):
     else:
         out_t = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
         my_rows = H
-    lanes = 1 if sortfirst else max(1, args.lanes)  # sort-first gathers after every frame on the frame's own stream
     ctx.set_frames_in_flight(lanes)
     # one output image per lane, as a swapchain has one image per frame in flight
-    outs = [out_t] + [torch.empty_like(out_t) for _ in range(lanes - 1)]
+    if sortfirst and args.backend == "nccl":
+        outs = list(comp.locals)
+    else:
+        outs = [out_t] + [torch.empty_like(out_t) for _ in range(lanes - 1)]
     if args.readback != "none" and not sortfirst:
         outs = [torch.empty(out_t.shape, dtype=torch.uint8, pin_memory=(args.readback == "pinned")) for _ in range(lanes)]
     fos = []
@@ -358,7 +363,9 @@ def run(args):
         if sortfirst:
             if args.backend != "nccl":
                 ctx.wait()  # the host-tensor rehearsal reads the rows on another stream
-            comp.gather()   # RCCL: queued on the renderer's stream behind the frame, no host wait
+                comp.gather()
+            else:
+                comp.gather(i % lanes)  # RCCL: queued on the frame's own stream behind the frame, no host wait
 
     def barrier():
         ctx.wait()

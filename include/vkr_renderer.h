@@ -242,9 +242,11 @@ VKR_API int vkr_render(vkr_context* ctx, const vkr_scene* scene, const vkr_frame
  *    tile bins outgrow their slice is reported with VKR_E_LIMIT by vkr_wait and the frame is incomplete (vkr_render
  *    would have grown the bins and rendered it again).
  *  - At most VKR_STATIC_MAX_PENDING such frames between two vkr_wait calls.
- *  - Frames run on the context's stream in submission order, among its vkr_render frames.  All contexts of a GPU
- *    share that GPU's array: allocation-free frames of two contexts (or two processes' worth of threads) that overlap
- *    on one GPU race; give each GPU one context that uses this entry point.
+ *  - Frames run on the context's stream in submission order, among its vkr_render frames.  All contexts of a
+ *    process on one GPU share that GPU's array, one context at a time: the context whose allocation-free frames are
+ *    pending owns the array until its vkr_wait (or its destruction), and a second context that submits meanwhile is
+ *    refused with VKR_E_LIMIT rather than left to race.  Calls on one context still must not overlap each other (a
+ *    context is not thread-safe).
  *  - Output pointers in device memory (or pinned host memory) keep the whole call free of staging allocations
  *    inside the HIP runtime. */
 #define VKR_STATIC_SCRATCH_BYTES (256u << 20)
@@ -327,11 +329,16 @@ VKR_API int vkr_composite_unique_id(uint8_t id[VKR_COMPOSITE_ID_BYTES]);
 VKR_API int vkr_compositor_create(vkr_context* ctx, const uint8_t id[VKR_COMPOSITE_ID_BYTES], int rank, int world,
                                   vkr_compositor** out);
 VKR_API void vkr_compositor_destroy(vkr_compositor* c);
-/* Collective, asynchronous on the context's stream (behind the frames queued there, in front of the next ones; no
- * host wait, no allocation): `local` = this rank's rows of the width x height RGBA8 frame as vkr_render delivered them
- * (device memory), `frame` = the whole frame on the receiving rank(s) (device memory; may be NULL elsewhere).
+/* Collective, asynchronous on the stream of the frame submitted last (vkr_context_frame_stream: behind that frame, in
+ * front of the next frame of the same lane; no host wait, no allocation): `local` = this rank's rows of the
+ * width x height RGBA8 frame as vkr_render delivered them (device memory; NULL only for a rank that owns no rows),
+ * `frame` = the whole frame on the receiving rank(s) (device memory; may be NULL elsewhere).
  * root >= 0: gather to that rank; root < 0: every rank receives the frame.  A band rendered straight into its place
- * (local == frame + first_row * width * 4) is not copied. */
+ * (local == frame + first_row * width * 4) is not copied; any other overlap of `local` and `frame` is refused
+ * (VKR_E_INVALID).  With more than one frame in flight (vkr_context_set_frames_in_flight) give every lane a `local`
+ * (and, where the frames are read, a `frame`) of its own, as a swapchain has one image per frame in flight: the
+ * exchange of one frame then runs under the rendering of the next.  Every rank must submit the same sequence of
+ * frames and exchanges with the same number of lanes. */
 VKR_API int vkr_composite_gather(vkr_compositor* c, uint32_t width, uint32_t height, uint32_t stripe_height, const void* local,
                                  void* frame, int root);
 /* The same exchange for rows of any size: the side buffers of a frame (tri_id and depth_bits are 4 bytes per pixel,
@@ -354,6 +361,12 @@ VKR_API int vkr_profile_get(vkr_context* ctx, int stage, double* total_ms, uint6
 /* The HIP stream (hipStream_t) the context launches on, and its device. */
 VKR_API void* vkr_context_stream(vkr_context* ctx);
 VKR_API int vkr_context_device(vkr_context* ctx);
+/* With frames in flight every lane has a stream of its own: the stream the frame submitted last runs on (the
+ * context's stream with one lane), and that lane's index (0 .. lanes - 1).  Work queued on this stream is ordered
+ * behind that frame and in front of the lane's next one.  The reference's counterpart is the per-swapchain-image
+ * command buffer and fence (main/main.cpp:466-476, 1268). */
+VKR_API void* vkr_context_frame_stream(vkr_context* ctx);
+VKR_API int vkr_context_frame_lane(vkr_context* ctx);
 
 /* Device memory for a host that has no HIP of its own (a plain C program): buffers on the context's GPU to render
  * into (vkr_frame_out accepts device pointers) and to exchange with vkr_composite_gather, and a copy in either

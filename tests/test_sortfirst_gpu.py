@@ -106,3 +106,69 @@ def test_rccl_compositor_with_one_rank(scene):
             lstc.free(); fstc.free()
     finally:
         comp.close(); local.free(); frame.free()
+
+
+def test_exchange_follows_the_frame_onto_its_lane(scene):
+    """Two frames in flight: consecutive frames run on lanes (streams) of their own, each with its own rows and its own
+    frame, and each exchange is queued on the stream of the frame it belongs to (vkr_context_frame_stream), so it
+    neither waits for nor overtakes the other lane's frame.  Bands in place, bands through a separate buffer and
+    stripes; the frames must be the ones rendered with one lane and a fence per frame."""
+    from conftest import DeviceBuffer
+    from vulkanrenderer_amd import abi, renderer
+    ctx, sc = scene
+    L = renderer.lib()
+    W, H = 640, 360
+    poses = [IDENTITY, pose_matrix(0.0, -1.0, -20.0, yaw=0.2), pose_matrix(0.0, -1.0, -40.0, yaw=-0.3), pose_matrix(1.0, -1.0, -60.0)]
+    refs = [sc.render(make(W, H, p, deferred=True), want=("rgba8",))["rgba8"] for p in poses]
+    comp = renderer.Compositor(ctx, renderer.composite_unique_id(), 0, 1)
+    locals_, frames = [DeviceBuffer(W * H * 4) for _ in range(2)], [DeviceBuffer(W * H * 4) for _ in range(2)]
+    try:
+        ctx.set_frames_in_flight(2)
+        lane0 = L.vkr_context_stream(ctx.h)
+        for sh, in_place in ((0, False), (0, True), (64, False)):
+            for f in frames:
+                f.zero()
+            got, streams = [], []
+            for i, pose in enumerate(poses):
+                k = i % 2
+                if i >= 2:  # the lane's previous frame is read back before the lane is reused
+                    assert L.vkr_wait_next_lane(ctx.h) == 0, L.vkr_last_error()
+                    got.append(frames[k].numpy((H, W, 4), np.uint8).copy())
+                fo = abi.FrameOut()
+                fo.rgba8 = frames[k].ptr if in_place else locals_[k].ptr
+                sc.submit(make(W, H, pose, deferred=True), fo)
+                assert L.vkr_context_frame_lane(ctx.h) == k
+                streams.append(L.vkr_context_frame_stream(ctx.h))
+                comp.gather(W, H, fo.rgba8, frames[k].ptr, root=0, stripe_height=sh)
+            ctx.wait()
+            got += [frames[0].numpy((H, W, 4), np.uint8).copy(), frames[1].numpy((H, W, 4), np.uint8).copy()]
+            assert streams[0] == lane0 and streams[1] != lane0 and streams[2] == streams[0] and streams[3] == streams[1]
+            for i in range(4):
+                assert np.array_equal(got[i], refs[i]), (sh, in_place, i)
+    finally:
+        ctx.wait()
+        ctx.set_frames_in_flight(1)
+        comp.close()
+        for b in locals_ + frames:
+            b.free()
+
+
+def test_gather_refuses_rows_that_overlap_the_frame(scene):
+    """`local` is either the rank's band in its place inside `frame` or a buffer apart from it."""
+    from conftest import DeviceBuffer
+    from vulkanrenderer_amd import renderer
+    ctx, sc = scene
+    W, H = 64, 64
+    comp = renderer.Compositor(ctx, renderer.composite_unique_id(), 0, 1)
+    frame = DeviceBuffer(W * H * 4 * 2)
+    try:
+        with pytest.raises(renderer.VkrError, match="overlaps"):
+            comp.gather(W, H, frame.ptr + W * 4 * 8, frame.ptr, root=0)                      # a band that is not in its place
+        with pytest.raises(renderer.VkrError, match="overlaps"):
+            comp.gather(W, H, frame.ptr, frame.ptr, root=0, stripe_height=32)                # stripes are never in place
+        with pytest.raises(renderer.VkrError, match="NULL"):
+            comp.gather(W, H, None, frame.ptr, root=0)                                       # this rank owns rows
+        comp.gather(W, H, frame.ptr + W * H * 4, frame.ptr, root=0)                          # apart: fine
+        ctx.wait()
+    finally:
+        comp.close(); frame.free()

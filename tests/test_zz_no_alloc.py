@@ -61,3 +61,38 @@ def test_static_entry_point_equals_vkr_render():
             assert np.array_equal(v, again[k]), k
     finally:
         sc.close(); ctx.close()
+
+
+def test_the_static_array_has_one_owner_per_gpu():
+    """Two contexts of one GPU share the static scratch array: while one has allocation-free frames pending the other
+    is refused (VKR_E_LIMIT) instead of overwriting them, and the fence of the first hands the array over."""
+    from vulkanrenderer_amd import renderer, scenes
+    L = renderer.lib()
+    packed = scenes.micro_scene()
+    a, b = renderer.Context(0), renderer.Context(0)
+    sa, sb = renderer.Scene(a, packed), renderer.Scene(b, packed)
+    try:
+        p = _params(256, 144, IDENTITY, deferred=True)
+        ref = sa.render(p)
+        bufs_a, fo_a = _outputs(p)
+        bufs_b, fo_b = _outputs(p)
+        assert L.vkr_render_static(a.h, sa.h, C.byref(p), C.byref(fo_a)) == 0, L.vkr_last_error()
+        assert L.vkr_render_static(b.h, sb.h, C.byref(p), C.byref(fo_b)) == 5          # VKR_E_LIMIT: a's frame is pending
+        assert b"another context" in L.vkr_last_error()
+        assert L.vkr_wait(a.h) == 0, L.vkr_last_error()
+        for k, v in ref.items():
+            assert np.array_equal(v, bufs_a[k]), k
+        assert L.vkr_render_static(b.h, sb.h, C.byref(p), C.byref(fo_b)) == 0, L.vkr_last_error()
+        assert L.vkr_render_static(a.h, sa.h, C.byref(p), C.byref(fo_a)) == 5          # and the other way round
+        assert L.vkr_wait(b.h) == 0, L.vkr_last_error()
+        for k, v in ref.items():
+            assert np.array_equal(v, bufs_b[k]), k
+        # a context destroyed with frames pending gives the array back
+        assert L.vkr_render_static(a.h, sa.h, C.byref(p), C.byref(fo_a)) == 0, L.vkr_last_error()
+        sa.close(); a.close(); sa = a = None
+        assert L.vkr_render_static(b.h, sb.h, C.byref(p), C.byref(fo_b)) == 0, L.vkr_last_error()
+        assert L.vkr_wait(b.h) == 0, L.vkr_last_error()
+    finally:
+        for x in (sa, sb, a, b):
+            if x is not None:
+                x.close()

@@ -14,6 +14,7 @@
 #include <exception>
 #include <new>
 #include <string>
+#include <mutex>
 #include <vector>
 
 // ---------------------------------------------------------------------------
@@ -157,7 +158,7 @@ struct vkr_context {
 	// on the same device that only this one hands frames to
 	std::vector<vkr_context*> lanes;
 	vkr_context* parent = nullptr;
-	uint32_t nextLane = 0;
+	uint32_t nextLane = 0, lastLane = 0; // lane the next frame goes to / the last one went to
 	// forward path: the light's depth pass runs on a helper context (stream + geometry scratch + the shadow map of its
 	// own) beside the camera's geometry and raster passes; the two streams fork and join through these events
 	vkr_context* shadowHelper = nullptr;
@@ -477,10 +478,31 @@ extern "C" void vkr_update_user_state(vkr_user_state* st, float elapsed)
 // ---------------------------------------------------------------------------
 // Device address of the static scratch array on `device` (which must be current), looked up once per device.
 #define VKR_MAX_DEVICES 64
+static std::mutex g_scratchMutex;                    // guards the two tables below
 static void* g_scratchBase[VKR_MAX_DEVICES];
+// The array is one per GPU and every context of that GPU cuts its allocation-free frames from it: the context whose
+// frames are pending owns it until its fence (vkr_wait) or its destruction; a second context that submits meanwhile
+// is refused instead of racing.
+static vkr_context* g_scratchOwner[VKR_MAX_DEVICES];
+static int static_scratch_acquire(vkr_context* t)
+{
+	std::lock_guard<std::mutex> lock(g_scratchMutex);
+	vkr_context*& owner = g_scratchOwner[t->device];
+	if (owner && owner != t)
+		return set_error(VKR_E_LIMIT, "vkr_render_static: another context has allocation-free frames pending on GPU %d, and the GPU's "
+		                              "static scratch array holds one context's frames at a time; call vkr_wait on that context first", t->device);
+	owner = t;
+	return VKR_OK;
+}
+static void static_scratch_release(vkr_context* t)
+{
+	std::lock_guard<std::mutex> lock(g_scratchMutex);
+	if (t->device >= 0 && t->device < VKR_MAX_DEVICES && g_scratchOwner[t->device] == t) g_scratchOwner[t->device] = nullptr;
+}
 static int static_scratch_base(int device, void** base)
 {
 	if (device < 0 || device >= VKR_MAX_DEVICES) return set_error(VKR_E_LIMIT, "device %d: the static scratch table holds %d devices", device, VKR_MAX_DEVICES);
+	std::lock_guard<std::mutex> lock(g_scratchMutex);
 	if (!g_scratchBase[device]) {
 		void* ptr = nullptr;
 		hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
@@ -566,6 +588,7 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 	for (auto& t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (auto e : c->eventPool) (void)hipEventDestroy(e);
 	if (c->hStatus) (void)hipHostFree(c->hStatus);
+	if (c->isStatic) static_scratch_release(c); // the stream was drained above
 	if (!c->isStatic) { // the allocation-free context borrows its owner's tables and stream
 		if (c->dDecode) (void)hipFree(c->dDecode);
 		if (c->dThresh) (void)hipFree(c->dThresh);
@@ -576,6 +599,13 @@ extern "C" void vkr_context_destroy(vkr_context* c)
 
 extern "C" void* vkr_context_stream(vkr_context* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int vkr_context_device(vkr_context* c) { return c ? c->device : -1; }
+extern "C" int vkr_context_frame_lane(vkr_context* c) { return (c && c->lastLane <= c->lanes.size()) ? (int)c->lastLane : 0; }
+extern "C" void* vkr_context_frame_stream(vkr_context* c)
+{
+	if (!c) return nullptr;
+	const uint32_t k = c->lastLane;
+	return (void*)((k && k <= c->lanes.size()) ? c->lanes[k - 1]->stream : c->stream);
+}
 
 extern "C" int vkr_device_malloc(vkr_context* c, size_t bytes, void** out)
 {
@@ -1482,6 +1512,7 @@ static int render_impl(vkr_context* c, const vkr_scene* s, const vkr_frame_param
 		// frames go round the lanes in submission order; the scene is read-only while rendering
 		const uint32_t k = c->nextLane;
 		c->nextLane = (k + 1) % (uint32_t)(c->lanes.size() + 1);
+		c->lastLane = k;
 		if (k) return render_impl(c->lanes[k - 1], s, fp, out);
 	}
 	HIP_CHECK(hipSetDevice(c->device));
@@ -1508,18 +1539,23 @@ static int render_static_impl(vkr_context* c, const vkr_scene* s, const vkr_fram
 	HIP_CHECK(hipSetDevice(c->device));
 	if (t->pending.size() >= VKR_STATIC_MAX_PENDING)
 		return set_error(VKR_E_LIMIT, "vkr_render_static: %d frames are pending, call vkr_wait first", VKR_STATIC_MAX_PENDING);
+	int rc;
+	if ((rc = static_scratch_acquire(t))) return rc;
 	DevBuf* b[VKR_CTX_NBUFS];
 	ctx_bufs(t, b);
 	for (DevBuf* d : b) { d->p = nullptr; d->cap = 0; }
 	t->arena.used = 0;
 	t->capScale = c->capScale; t->binFloor = c->binFloor; // what vkr_render has learnt about this scene's bins
 	t->zeroCapTiles = 0; // the counter sets are re-cut and zeroed for this frame (the array keeps the last frame's contents)
-	int rc;
-	if ((rc = ensure_status(t, 2))) return rc;
+	if ((rc = ensure_status(t, 2))) { if (t->pending.empty()) static_scratch_release(t); return rc; }
 	PendingFrame pf;
 	pf.scene = s; pf.params = *fp; pf.out = *out; pf.statusSlot = t->statusUsed; pf.nPasses = 0;
 	memset(&t->hStatus[pf.statusSlot], 0, sizeof(PassStatus) * 2);
-	if ((rc = submit_frame(t, s, pf.params, pf.out, pf.statusSlot, &pf.nPasses))) { recover_failed_submit(t); return rc; }
+	if ((rc = submit_frame(t, s, pf.params, pf.out, pf.statusSlot, &pf.nPasses))) {
+		recover_failed_submit(t);
+		if (t->pending.empty()) static_scratch_release(t);
+		return rc;
+	}
 	t->statusUsed += 2;
 	t->pending.push_back(pf); // capacity reserved at creation
 	return VKR_OK;
@@ -1538,6 +1574,7 @@ static int wait_static(vkr_context* t)
 				                            "the frame is incomplete, render it with vkr_render", t->hStatus[pf.statusSlot + k].binTotal);
 	t->pending.clear();
 	t->statusUsed = 0;
+	static_scratch_release(t); // nothing of this context is in flight any more
 	return rc;
 }
 

@@ -160,13 +160,13 @@ extern "C" void vkr_compositor_destroy(vkr_compositor* c)
 {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
-	(void)hipStreamSynchronize((hipStream_t)vkr_context_stream(c->ctx));
+	(void)hipDeviceSynchronize(); // exchanges may be queued on any lane's stream
 	if (c->comm) (void)g_rccl.CommDestroy(c->comm);
 	delete c;
 }
 
-// One grouped exchange on the context's stream, behind the frames already queued there and in front of whatever is
-// queued next (so the next frame cannot overwrite `local` under the send).  Each contiguous run of rows is one
+// One grouped exchange on the stream of the frame submitted last, behind that frame and in front of whatever that
+// lane is handed next (so its next frame cannot overwrite `local` under the send).  Each contiguous run of rows is one
 // transfer: a band is one run; a stripe partition has one run per stripe.  A rank's own rows travel through RCCL as
 // well (send to self) unless they already sit in place.
 extern "C" int vkr_composite_gather(vkr_compositor* c, uint32_t width, uint32_t height, uint32_t stripe_height, const void* local,
@@ -182,12 +182,28 @@ extern "C" int vkr_composite_gather_rows(vkr_compositor* c, size_t row_bytes, ui
 	if (root >= c->world) return vkr_set_error_ext(VKR_E_INVALID, "vkr_composite_gather: root %d of %d", root, c->world);
 	const bool receiver = root < 0 || root == c->rank;
 	if (receiver && !frame) return vkr_set_error_ext(VKR_E_INVALID, "vkr_composite_gather: this rank receives the frame but `frame` is NULL");
-	if (!local) return vkr_set_error_ext(VKR_E_INVALID, "vkr_composite_gather: `local` is NULL");
-	if (hipSetDevice(c->device) != hipSuccess) return vkr_set_error_ext(VKR_E_DEVICE, "hipSetDevice(%d) failed", c->device);
-	hipStream_t stream = (hipStream_t)vkr_context_stream(c->ctx);
 	const size_t rowBytes = row_bytes;
 	const uint32_t W = (uint32_t)c->world;
 	const uint32_t runH = stripe_height ? stripe_height : 0;
+	{
+		// a rank without rows (more ranks than bands of two rows) has nothing to send and needs no `local`
+		uint32_t myFirst = 0, myCount = 0;
+		vkr_sortfirst_rows(height, W, (uint32_t)c->rank, stripe_height, &myFirst, &myCount);
+		if (!local && myCount) return vkr_set_error_ext(VKR_E_INVALID, "vkr_composite_gather: `local` is NULL but this rank owns %u rows", myCount);
+		// `local` may be the rank's band in its place inside `frame` (then nothing is copied); any other overlap would
+		// make a send and a receive of one group touch the same bytes
+		if (local && frame && myCount) {
+			const char* l0 = (const char*)local; const char* l1 = l0 + (size_t)myCount * rowBytes;
+			const char* f0 = (const char*)frame; const char* f1 = f0 + (size_t)height * rowBytes;
+			const bool inPlace = !runH && l0 == f0 + (size_t)myFirst * rowBytes;
+			if (!inPlace && l0 < f1 && f0 < l1)
+				return vkr_set_error_ext(VKR_E_INVALID, "vkr_composite_gather: `local` overlaps `frame` without being this rank's band in its place");
+		}
+	}
+	if (hipSetDevice(c->device) != hipSuccess) return vkr_set_error_ext(VKR_E_DEVICE, "hipSetDevice(%d) failed", c->device);
+	// the stream of the frame submitted last: with frames in flight that is the lane's own stream, so the exchange is
+	// ordered behind that frame only and the next frame (on another lane) renders meanwhile
+	hipStream_t stream = (hipStream_t)vkr_context_frame_stream(c->ctx);
 	RCCL_CHECK(g_rccl.GroupStart());
 	ncclResult_t bad = ncclSuccess;
 	for (uint32_t r = 0; r < W && bad == ncclSuccess; r++) {

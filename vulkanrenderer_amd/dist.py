@@ -103,10 +103,13 @@ BandCompositor = HostCompositor
 
 
 class RcclCompositor:
-    """Thin caller of the library's compositor (vkr_compositor_*): the rows go over RCCL / xGMI on the renderer's own
-    stream.  The unique id is created on rank 0 and broadcast over torch.distributed, which the host already has."""
+    """Thin caller of the library's compositor (vkr_compositor_*): the rows go over RCCL / xGMI on the stream of the
+    frame they belong to.  The unique id is created on rank 0 and broadcast over torch.distributed, which the host
+    already has.  `lanes` = frames in flight on the context: every lane renders into rows of its own (`locals[k]`) and,
+    on the receiving ranks, into a frame of its own (`frames[k]`), so the exchange of one frame runs under the
+    rendering of the next."""
 
-    def __init__(self, ctx, width, height, rank, world, device, stripe_height=0, everywhere=False):
+    def __init__(self, ctx, width, height, rank, world, device, stripe_height=0, everywhere=False, lanes=1):
         from . import renderer
         self.ctx, self.width, self.height, self.rank, self.world = ctx, width, height, rank, world
         self.stripe_height, self.everywhere = stripe_height, everywhere
@@ -120,17 +123,24 @@ class RcclCompositor:
         first, count = renderer.sortfirst_rows(height, world, rank, stripe_height)
         self.first_row, self.my_rows = first, count
         receives = everywhere or rank == 0
-        self.frame = torch.zeros((height, width, 4), dtype=torch.uint8, device=device) if receives else None
-        if receives and not stripe_height:
-            self.local = self.frame[first:first + count]  # a band is rendered straight into its place
-        else:
-            self.local = torch.zeros((max(count, 1), width, 4), dtype=torch.uint8, device=device)
+        self.frames, self.locals = [], []
+        for _ in range(max(1, lanes)):
+            frame = torch.zeros((height, width, 4), dtype=torch.uint8, device=device) if receives else None
+            if receives and not stripe_height:
+                local = frame[first:first + count]  # a band is rendered straight into its place
+            else:
+                local = torch.zeros((max(count, 1), width, 4), dtype=torch.uint8, device=device)
+            self.frames.append(frame)
+            self.locals.append(local)
+        self.frame, self.local = self.frames[0], self.locals[0]
 
-    def gather(self):
-        """Queues the exchange behind the frame just submitted; returns at once.  `frame` is complete after ctx.wait()."""
-        self.comp.gather(self.width, self.height, self.local.data_ptr(), self.frame.data_ptr() if self.frame is not None else None,
-                         root=-1 if self.everywhere else 0, stripe_height=self.stripe_height)
-        return self.frame
+    def gather(self, lane=0):
+        """Queues the exchange behind the frame just submitted (which went to `lane`); returns at once.  `frames[lane]` is
+        complete after ctx.wait()."""
+        frame, local = self.frames[lane], self.locals[lane]
+        self.comp.gather(self.width, self.height, local.data_ptr() if self.my_rows else None,
+                         frame.data_ptr() if frame is not None else None, root=-1 if self.everywhere else 0, stripe_height=self.stripe_height)
+        return frame
 
     def close(self):
         self.comp.close()

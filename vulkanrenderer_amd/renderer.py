@@ -28,6 +28,7 @@ EXPORTS = [
     "vkr_frame_params_set_modes", "vkr_render_static", "vkr_context_device", "vkr_sortfirst_rows",
     "vkr_composite_unique_id", "vkr_compositor_create", "vkr_compositor_destroy", "vkr_composite_gather",
     "vkr_device_malloc", "vkr_device_free", "vkr_device_copy", "vkr_composite_gather_rows",
+    "vkr_context_frame_stream", "vkr_context_frame_lane",
 ]
 
 
@@ -85,6 +86,9 @@ def lib():
         L.vkr_free.restype = None
         L.vkr_context_stream.restype = C.c_void_p
         L.vkr_context_stream.argtypes = [C.c_void_p]
+        L.vkr_context_frame_stream.restype = C.c_void_p
+        L.vkr_context_frame_stream.argtypes = [C.c_void_p]
+        L.vkr_context_frame_lane.argtypes = [C.c_void_p]
         L.vkr_context_set_frames_in_flight.argtypes = [C.c_void_p, C.c_uint32]
         L.vkr_context_device.argtypes = [C.c_void_p]
         L.vkr_sortfirst_rows.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
