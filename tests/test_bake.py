@@ -133,11 +133,17 @@ def test_zstd_decoder_bounds_what_a_small_input_can_ask_for():
     assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < (1 << 20)   # KiB: less than 1 GiB more
     # an RLE block that claims 2 MiB (blocks regenerate at most 128 KiB)
     frame = magic + bytes([0x00, 0x58]) + struct.pack("<I", ((2 << 20) - 1) << 3 | (1 << 1) | 1)[:3] + b"x"
-    with pytest.raises(bake.BakeError, match="128 KiB"):
+    with pytest.raises(bake.BakeError, match="block maximum"):
         bake.zstd_decode(frame)
     # the largest legal RLE block is fine
     frame = magic + bytes([0x00, 0x58]) + struct.pack("<I", (128 << 10) << 3 | (1 << 1) | 1)[:3] + b"x"
     assert bake.zstd_decode(frame) == b"x" * (128 << 10)
+    # a window smaller than 128 KiB lowers the block maximum with it: 1 KiB window (descriptor 0x00), 2 KiB RLE block
+    frame = magic + bytes([0x00, 0x00]) + struct.pack("<I", (2 << 10) << 3 | (1 << 1) | 1)[:3] + b"x"
+    with pytest.raises(bake.BakeError, match="block maximum"):
+        bake.zstd_decode(frame)
+    frame = magic + bytes([0x00, 0x00]) + struct.pack("<I", (1 << 10) << 3 | (1 << 1) | 1)[:3] + b"x"
+    assert bake.zstd_decode(frame) == b"x" * (1 << 10)
 
 
 def test_baked_file_loads_in_the_reference_loader_format(tmp_path):

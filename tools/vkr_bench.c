@@ -9,12 +9,15 @@
  *   vkr_bench scene.comp5892mesh [--width W] [--height H] [--frames N]
  *             [--first I] [--mode deferred|forward|mosaic|debug2..6]
  *             [--fused] [--lanes L] [--device D] [--png out.png]
- *             [--ranks N --rank R --uid-file F [--stripe-height S]]
+ *             [--ranks N --rank R --uid-file F [--session S] [--stripe-height S]]
  *
  * With --ranks the program is one of N processes (one per GPU, started by whatever the host has: a shell loop,
  * mpirun, a job scheduler) that share every frame sort-first: each renders its rows - a band, or with
  * --stripe-height every N-th stripe - into device memory, and the rows meet on rank 0 through the library's RCCL
- * compositor.  Rank 0 creates the communicator's id and leaves it in file F, the others pick it up there.
+ * compositor.  Rank 0 creates the communicator's id and leaves it in file F, the others pick it up there.  The file
+ * also names the session it belongs to (--session S; by default the id of the process that started the ranks), and a
+ * reader takes no id of another session: rank 0 removes whatever an earlier run left behind before it writes, and
+ * removes its own file once every rank has joined, but a reader may look before either has happened.
  *
  * Build: make -C tools   (gcc; no HIP headers needed, the ABI is plain C)
  */
@@ -26,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 static double now_s(void)
 {
@@ -46,25 +50,34 @@ static void fly_pose(int i, float m[16])
 	m[13] = -1.0f; m[14] = (float)(-90.0 * (double)i / 511.0); m[15] = 1.0f;
 }
 
-/* the communicator id travels through a file: written under another name and renamed, so a reader never sees half of it */
-static int publish_id(const char* path, const uint8_t* id)
+/* the communicator id travels through a file - the id, then the session's name - written under another name and
+ * renamed, so a reader never sees half of it */
+#define SESSION_BYTES 64
+static int publish_id(const char* path, const uint8_t* id, const char* session)
 {
 	char tmp[4096];
+	char tag[SESSION_BYTES];
+	memset(tag, 0, sizeof tag);
+	snprintf(tag, sizeof tag, "%s", session);
 	snprintf(tmp, sizeof tmp, "%s.tmp", path);
+	(void)remove(path); /* an earlier run's file */
 	FILE* f = fopen(tmp, "wb");
 	if (!f) return 1;
-	const int ok = fwrite(id, 1, VKR_COMPOSITE_ID_BYTES, f) == VKR_COMPOSITE_ID_BYTES;
+	const int ok = fwrite(id, 1, VKR_COMPOSITE_ID_BYTES, f) == VKR_COMPOSITE_ID_BYTES && fwrite(tag, 1, sizeof tag, f) == sizeof tag;
 	return (fclose(f) == 0 && ok && rename(tmp, path) == 0) ? 0 : 1;
 }
 
-static int fetch_id(const char* path, uint8_t* id)
+static int fetch_id(const char* path, uint8_t* id, const char* session)
 {
+	char want[SESSION_BYTES], tag[SESSION_BYTES];
+	memset(want, 0, sizeof want);
+	snprintf(want, sizeof want, "%s", session);
 	for (int tries = 0; tries < 600; tries++) { /* up to a minute */
 		FILE* f = fopen(path, "rb");
 		if (f) {
-			const int ok = fread(id, 1, VKR_COMPOSITE_ID_BYTES, f) == VKR_COMPOSITE_ID_BYTES;
+			const int ok = fread(id, 1, VKR_COMPOSITE_ID_BYTES, f) == VKR_COMPOSITE_ID_BYTES && fread(tag, 1, sizeof tag, f) == sizeof tag;
 			fclose(f);
-			if (ok) return 0;
+			if (ok && !memcmp(tag, want, sizeof tag)) return 0; /* anything else is another run's file: keep waiting for ours */
 		}
 		{ struct timespec nap = { 0, 100000000L }; nanosleep(&nap, NULL); }
 	}
@@ -84,6 +97,7 @@ int main(int argc, char** argv)
 	int frames = 64, first = 0, device = 0, fused = 0, ranks = 0, rank = 0;
 	unsigned stripeH = 0;
 	const char* uidFile = NULL;
+	const char* session = NULL;
 	for (int i = 1; i < argc; i++) {
 		const char* a = argv[i];
 		const char* v = (i + 1 < argc) ? argv[i + 1] : NULL;
@@ -100,6 +114,7 @@ int main(int argc, char** argv)
 		else if (!strcmp(a, "--ranks")) { ranks = atoi(v); i++; }
 		else if (!strcmp(a, "--rank")) { rank = atoi(v); i++; }
 		else if (!strcmp(a, "--uid-file")) { uidFile = v; i++; }
+		else if (!strcmp(a, "--session")) { session = v; i++; }
 		else if (!strcmp(a, "--stripe-height")) { stripeH = (unsigned)atoi(v); i++; }
 		else if (a[0] == '-') { fprintf(stderr, "vkr_bench: unknown option %s\n", a); return 2; }
 		else scenePath = a;
@@ -107,11 +122,15 @@ int main(int argc, char** argv)
 	if (!scenePath || frames < 1 || lanes < 1 || lanes > VKR_MAX_FRAMES_IN_FLIGHT || (ranks && (ranks < 1 || rank < 0 || rank >= ranks || !uidFile))) {
 		fprintf(stderr, "usage: vkr_bench scene.comp5892mesh [--width W] [--height H] [--frames N] [--first I] "
 		                "[--mode deferred|forward|mosaic|debug2..6] [--fused] [--lanes 1..%d] [--device D] [--png out.png] "
-		                "[--ranks N --rank R --uid-file F [--stripe-height S]]\n",
+		                "[--ranks N --rank R --uid-file F [--session S] [--stripe-height S]]\n",
 		        VKR_MAX_FRAMES_IN_FLIGHT);
 		return 2;
 	}
-	if (ranks) lanes = 1; /* the exchange is queued behind every frame on the frame's own stream */
+	char sessionDefault[SESSION_BYTES];
+	if (!session) { /* the ranks of one launch share their parent */
+		snprintf(sessionDefault, sizeof sessionDefault, "parent-%ld", (long)getppid());
+		session = sessionDefault;
+	}
 	/* UserState's mode fields (main/main.cpp:117-119) */
 	int debug = 1, mosaic = 0, deferred = 0;
 	if (!strcmp(mode, "deferred")) deferred = 1;
@@ -145,18 +164,21 @@ int main(int argc, char** argv)
 
 	/* sort-first: this rank's rows go into `local` (device memory), the whole frame arrives in `frame` on rank 0 */
 	vkr_compositor* comp = NULL;
-	void* local = NULL; void* frame = NULL;
+	void* local[VKR_MAX_FRAMES_IN_FLIGHT] = { 0 }; void* frame[VKR_MAX_FRAMES_IN_FLIGHT] = { 0 }; /* one set per frame in flight */
 	uint32_t firstRow = 0, myRows = height;
 	if (ranks) {
 		uint8_t id[VKR_COMPOSITE_ID_BYTES];
 		if (rank == 0) {
 			if (vkr_composite_unique_id(id)) return fail("vkr_composite_unique_id");
-			if (publish_id(uidFile, id)) { fprintf(stderr, "vkr_bench: cannot write %s\n", uidFile); return 1; }
-		} else if (fetch_id(uidFile, id)) { fprintf(stderr, "vkr_bench: no communicator id in %s\n", uidFile); return 1; }
+			if (publish_id(uidFile, id, session)) { fprintf(stderr, "vkr_bench: cannot write %s\n", uidFile); return 1; }
+		} else if (fetch_id(uidFile, id, session)) { fprintf(stderr, "vkr_bench: no communicator id of session %s in %s\n", session, uidFile); return 1; }
 		if (vkr_compositor_create(ctx, id, rank, ranks, &comp)) return fail("vkr_compositor_create");
+		if (rank == 0) (void)remove(uidFile); /* every rank has joined, so every rank has read it */
 		if (vkr_sortfirst_rows(height, (uint32_t)ranks, (uint32_t)rank, stripeH, &firstRow, &myRows)) return fail("vkr_sortfirst_rows");
-		if (vkr_device_malloc(ctx, (size_t)(myRows ? myRows : 1) * width * 4, &local)) return fail("vkr_device_malloc");
-		if (rank == 0 && vkr_device_malloc(ctx, imageBytes, &frame)) return fail("vkr_device_malloc");
+		for (unsigned l = 0; l < lanes; l++) {
+			if (vkr_device_malloc(ctx, (size_t)(myRows ? myRows : 1) * width * 4, &local[l])) return fail("vkr_device_malloc");
+			if (rank == 0 && vkr_device_malloc(ctx, imageBytes, &frame[l])) return fail("vkr_device_malloc");
+		}
 		if (stripeH) fp.stripes = VKR_STRIPES(stripeH, ranks, rank);
 		else { fp.rect_x0 = 0; fp.rect_y0 = firstRow; fp.rect_x1 = width; fp.rect_y1 = firstRow + myRows; }
 	}
@@ -175,12 +197,14 @@ int main(int argc, char** argv)
 		vkr_make_uniforms(&fp.uniforms, width, height, cam, debug); /* update_scene_uniforms & co., main/main.cpp:1313-1365 */
 		vkr_frame_out fo;
 		memset(&fo, 0, sizeof fo);
-		fo.rgba8 = ranks ? (uint8_t*)local : images[submitted % lanes];
+		const unsigned lane = submitted % lanes;
+		fo.rgba8 = ranks ? (uint8_t*)local[lane] : images[lane];
 		/* this lane's image is about to be reused: wait for the frame that was rendered into it, as the
 		 * reference waits on the fence of the swapchain image it is about to record into (main/main.cpp:1268) */
 		if (vkr_wait_next_lane(ctx)) return fail("vkr_wait_next_lane");
 		if (myRows && vkr_render(ctx, scene, &fp, &fo)) return fail("vkr_render");
-		if (ranks && vkr_composite_gather(comp, width, height, stripeH, local, frame, 0)) return fail("vkr_composite_gather");
+		/* queued on the lane the frame went to: the rows leave while the next frame renders on the other lane */
+		if (ranks && vkr_composite_gather(comp, width, height, stripeH, myRows ? local[lane] : NULL, frame[lane], 0)) return fail("vkr_composite_gather");
 		submitted++;
 	}
 	if (vkr_wait(ctx)) return fail("vkr_wait");
@@ -193,11 +217,10 @@ int main(int argc, char** argv)
 	       fused, width, height, frames, lanes, dt / frames * 1e3, frames / dt, ranks ? "device rows, gathered on rank 0" : "host images",
 	       ranks ? ranks : 1, rank, (unsigned)myRows);
 	int rc = 0;
-	if (ranks && rank == 0 && vkr_device_copy(ctx, images[0], frame, imageBytes)) rc = fail("vkr_device_copy");
+	if (ranks && rank == 0 && vkr_device_copy(ctx, images[0], frame[(submitted - 1) % lanes], imageBytes)) rc = fail("vkr_device_copy");
 	if (png && (!ranks || rank == 0) && vkr_write_png_file(png, images[ranks ? 0 : (submitted - 1) % lanes], width, height, 0)) rc = fail("vkr_write_png_file");
 	if (comp) vkr_compositor_destroy(comp);
-	vkr_device_free(ctx, local);
-	vkr_device_free(ctx, frame);
+	for (unsigned l = 0; l < lanes; l++) { vkr_device_free(ctx, local[l]); vkr_device_free(ctx, frame[l]); }
 	for (unsigned l = 0; l < lanes; l++) free(images[l]);
 	vkr_scene_destroy(scene);
 	vkr_context_destroy(ctx);

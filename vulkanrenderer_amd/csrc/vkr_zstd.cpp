@@ -202,7 +202,7 @@ size_t huf_read(HufTable& h, const uint8_t* src, size_t len)
 		used = 1 + (size_t)header;
 		if (used > len || !header) bad("Huffman weights run past their section");
 		FseTable t;
-		const size_t th = fse_read(t, src + 1, header, 7, 256);
+		const size_t th = fse_read(t, src + 1, header, 6, 12); // weights 0..11 with an accuracy log of at most 6 (RFC 8878 4.2.1.1)
 		if (th >= (size_t)header) bad("Huffman weights: empty stream");
 		BackBits in(src + 1 + th, header - th);
 		uint32_t s1 = (uint32_t)in.read(t.accuracy), s2 = (uint32_t)in.read(t.accuracy);
@@ -293,7 +293,7 @@ void decode_block(FrameState& st, const uint8_t* src, size_t len, std::vector<ui
 		pos += regen;
 	} else if (ltype == 1) {
 		if (pos + 1 > len) bad("RLE literals run past the block");
-		std::memset(lit.data(), src[pos], regen);
+		if (regen) std::memset(lit.data(), src[pos], regen);
 		pos += 1;
 	} else {
 		if (pos + comp > len) bad("compressed literals run past the block");
@@ -448,6 +448,8 @@ size_t decode_frame(const uint8_t* src, size_t len, std::vector<uint8_t>& out)
 	if (fcsBytes) out.reserve(out.size() + (size_t)(contentSize < ((uint64_t)256 << 20) ? contentSize : ((uint64_t)256 << 20)));
 	FrameState st;
 	std::vector<uint8_t> lit;
+	// Block_Maximum_Size: the smaller of the window and 128 KiB (RFC 8878 3.1.1.2.4)
+	const size_t blockMax = (size_t)(windowSize < (128u << 10) ? windowSize : (128u << 10));
 	for (;;) {
 		if (pos + 3 > len) bad("truncated block header");
 		const uint32_t bh = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
@@ -455,7 +457,7 @@ size_t decode_frame(const uint8_t* src, size_t len, std::vector<uint8_t>& out)
 		const int last = bh & 1, type = (bh >> 1) & 3;
 		const size_t size = bh >> 3;
 		if (type == 3) bad("reserved block type");
-		if (type != 2 && size > (128u << 10)) bad("block larger than 128 KiB");
+		if (type != 2 && size > blockMax) bad("block larger than the frame's block maximum");
 		if (type == 0) {
 			if (pos + size > len) bad("raw block runs past the input");
 			out.insert(out.end(), src + pos, src + pos + size);
@@ -466,10 +468,10 @@ size_t decode_frame(const uint8_t* src, size_t len, std::vector<uint8_t>& out)
 			pos += 1;
 		} else {
 			if (pos + size > len) bad("compressed block runs past the input");
-			if (size > (128u << 10)) bad("compressed block larger than 128 KiB");
+			if (size > blockMax) bad("compressed block larger than the frame's block maximum");
 			const size_t before = out.size();
 			decode_block(st, src + pos, size, out, frameStart, windowSize, lit);
-			if (out.size() - before > (128u << 10)) bad("block regenerates more than the block maximum");
+			if (out.size() - before > blockMax) bad("block regenerates more than the block maximum");
 			pos += size;
 		}
 		if (last) break;
