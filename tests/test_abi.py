@@ -113,3 +113,14 @@ def test_sortfirst_rows_partition_the_frame():
                     assert count == len(rows) and (count == 0 or rows[0] == first)
                     owner[rows] += 1
                 assert np.all(owner == 1)
+
+
+def test_workgroup_placement_maps_are_bijections(tmp_path):
+    """The screen-walking kernels take their place on the screen from a map of the dispatch index (runs of neighbouring
+    workgroups per XCD, vulkanrenderer_amd/csrc/vkr_place.h).  The header is plain C++: compiled for the host, every map
+    must cover every grid exactly once - a place taken twice would leave pixels undrawn."""
+    import subprocess
+    exe = str(tmp_path / "place_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tools", "place_check.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "bijective", out.stdout + out.stderr

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 	__shared__ unsigned long long tb64[MODE == RASTER_VIS ? VKR_TILE_PIX : 1];
 	__shared__ uint32_t tb32[MODE == RASTER_VIS ? 1 : VKR_TILE_PIX];
 	__shared__ int sAnyAlpha;
-	const uint32_t tile = blockIdx.x;
+	const uint32_t tile = blockIdx.x; // dispatch order: runs of tiles per XCD bought no time and cost L2 misses here (27 -> 31 MB)
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
 	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = vkr_view_gy(a.view, ty * VKR_TILE);
 	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = oy + (int)min((uint32_t)VKR_TILE, a.view.rows - ty * VKR_TILE) - 1; // inclusive
@@ -409,7 +409,9 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 	const bool spare = a.alphaTileCount[0] * 4u <= ALPHA_BUSY;
 	uint32_t tile, quad, sub = 0, split = 1;
 	if (blockIdx.x < nQuads) {
-		tile = blockIdx.x / 4; quad = blockIdx.x & 3u;
+		// the four quadrants of a tile read the same bin section and records: one XCD for all of them
+		const uint32_t q = vkr_xcd_place<4u>(blockIdx.x, nQuads);
+		tile = q / 4; quad = q & 3u;
 		const uint32_t flag = a.alphaTiles[tile];
 		if (!flag) return;
 		if (spare && flag >= 2u && (flag - 2u) * 4u * (ALPHA_SPLIT - 1u) + 4u * (ALPHA_SPLIT - 1u) <= ALPHA_HELPERS) split = ALPHA_SPLIT;

@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void k_resolve_gbuf(ResolveArgs a)
 {
 	__shared__ float sDec[256];
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.rows;
-	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+	uint32_t bx, by;
+	vkr_screen_place(bx, by);
+	const uint32_t x = bx * 16 + (threadIdx.x & 15), y = by * 16 + (threadIdx.x >> 4);
 	const bool inside = x < rw && y < rh;
 	const size_t p = (size_t)y * rw + x;
 	// the visibility key is requested before the decode table's round trip and the barrier behind it
@@ -192,7 +194,9 @@ __global__ __launch_bounds__(256) void k_resolve_forward(ResolveArgs a)
 	__shared__ float sDec[256];
 	__shared__ float sT[257];
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.rows;
-	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+	uint32_t bx, by;
+	vkr_screen_place(bx, by);
+	const uint32_t x = bx * 16 + (threadIdx.x & 15), y = by * 16 + (threadIdx.x >> 4);
 	const bool inside = x < rw && y < rh;
 	const size_t p = (size_t)y * rw + x;
 	const unsigned long long key = inside ? a.vis[p] : 0ull; // requested before the tables' round trip
@@ -254,7 +258,9 @@ __global__ __launch_bounds__(256) void k_resolve_debug(ResolveArgs a)
 	vkr_load_srgb_table(sT, a.sc.srgbThresh);
 	__syncthreads();
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.rows;
-	const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+	uint32_t bx, by;
+	vkr_screen_place(bx, by);
+	const uint32_t x = bx * 16 + (threadIdx.x & 15), y = by * 16 + (threadIdx.x >> 4);
 	if (x >= rw || y >= rh) return;
 	const size_t p = (size_t)y * rw + x;
 	const int px = (int)(a.view.x0 + x), py = vkr_view_gy(a.view, y);
@@ -322,7 +328,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	__shared__ float sT[257];
 	const uint32_t rw = a.view.x1 - a.view.x0, rh = a.view.rows;
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-	const uint32_t x = blockIdx.x * 16u + (wv & 1u) * 8u + (lane & 7u), y = blockIdx.y * 16u + (wv >> 1) * 8u + (lane >> 3);
+	uint32_t bx, by;
+	vkr_screen_place(bx, by);
+	const uint32_t x = bx * 16u + (wv & 1u) * 8u + (lane & 7u), y = by * 16u + (wv >> 1) * 8u + (lane >> 3);
 	const bool inside = x < rw && y < rh;
 	const size_t p = (size_t)y * rw + x;
 	const unsigned long long key = inside ? a.vis[p] : 0ull; // requested before the tables' round trip

@@ -114,6 +114,15 @@ struct ViewDev {
 };
 
 // frame row of local row ly
+#include "vkr_place.h"
+// (blockIdx.x, blockIdx.y) of the place this workgroup of a screen-walking kernel takes (vkr_place.h): blocks of 8 x 8
+// workgroups per XCD on large grids, 4 x 4 on small ones, where 8 x 8 would leave an XCD only a handful of blocks.
+__device__ __forceinline__ void vkr_screen_place(uint32_t& bx, uint32_t& by)
+{
+	if (gridDim.x * gridDim.y >= 16384u) vkr_xcd_place_2d<8u, 8u>(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
+	else vkr_xcd_place_2d<4u, 4u>(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
+}
+
 __host__ __device__ __forceinline__ int vkr_view_gy(const ViewDev& v, uint32_t ly)
 {
 	if (v.stripeN <= 1u) return (int)(v.y0 + ly);

@@ -81,7 +81,10 @@ __device__ __forceinline__ uint32_t vkr_light_pixel(const LightArgs& a, const fl
 	}
 	float S0 = 0.0f;                          // sum 1/d^2 (ambient)
 	float S1[3] = { 0, 0, 0 }, S2[3] = { 0, 0, 0 }, S3[3] = { 0, 0, 0 }; // SAMECOL: only [0] is used
-#pragma unroll 3
+#ifndef VKR_LIGHT_UNROLL
+#define VKR_LIGHT_UNROLL 3 // measured: 3 lights per trip beats 1, 7 and 21 (the whole table in scalar registers ahead of the loop)
+#endif
+#pragma unroll VKR_LIGHT_UNROLL
 	for (int i = 0; i < VKR_NUM_LIGHTS_K; i++) {
 		const float Lx = a.lightPos[i][0] - Px, Ly = a.lightPos[i][1] - Py, Lz = a.lightPos[i][2] - Pz;
 		const float d2 = Lx * Lx + Ly * Ly + Lz * Lz;
