@@ -365,14 +365,16 @@ __global__ __launch_bounds__(256) void k_count_big(SetupArgs a)
 __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ count, const uint32_t* __restrict__ countA,
                                                       const uint32_t* __restrict__ countBig,
                                                       uint32_t* __restrict__ offset, uint32_t* __restrict__ cursor, uint32_t nTiles,
-                                                      uint32_t cap, uint32_t* overflow, uint32_t* statusOut)
+                                                      uint32_t cap, uint32_t* overflow, uint32_t* statusOut, uint32_t* __restrict__ tileOrder)
 {
 	// 8192 tiles per round: the 24 loads of a thread are issued together, the eight 1024-wide scans run from
 	// registers and meet in one barrier (a round per 1024 tiles is three barriers and a load round trip each)
 	__shared__ uint32_t wsum[8][16];
 	__shared__ uint32_t carry;
+	__shared__ uint32_t classCount[32]; // tiles per bin-length class (tileOrder only)
 	uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	if (tid == 0) carry = 0;
+	if (tid < 32) classCount[tid] = 0;
 	__syncthreads();
 	for (uint32_t base = 0; base < nTiles; base += 8192) {
 		uint32_t v[8], s[8];
@@ -380,6 +382,8 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 		for (int j = 0; j < 8; j++) {
 			const uint32_t i = base + j * 1024 + tid;
 			v[j] = (i < nTiles) ? count[i] + countA[i] + countBig[i] : 0u;
+			// class 0 = the longest bins: 31 - floor(log2(n | 1))
+			if (tileOrder && i < nTiles) atomicAdd(&classCount[__clz((int)(v[j] | 1u))], 1u);
 		}
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
@@ -410,6 +414,20 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 		__syncthreads();
 		if (tid == 0) carry = running;
 		__syncthreads();
+	}
+	if (tileOrder) {
+		// A counting sort of the tiles by class, longest bins first: a kernel that gives one workgroup to every tile
+		// and whose time is set by its few deep tiles (k_overshade) starts those first.  The order inside a class is
+		// whatever the atomics make it; it schedules work and decides no result.
+		if (tid == 0) {
+			uint32_t run = 0;
+			for (int k = 0; k < 32; k++) { const uint32_t c = classCount[k]; classCount[k] = run; run += c; }
+		}
+		__syncthreads();
+		for (uint32_t i = tid; i < nTiles; i += 1024u) {
+			const uint32_t n = count[i] + countA[i] + countBig[i];
+			tileOrder[atomicAdd(&classCount[__clz((int)(n | 1u))], 1u)] = i;
+		}
 	}
 	if (tid == 0) {
 		offset[nTiles] = carry;
@@ -500,9 +518,9 @@ void vkr_launch_setup(hipStream_t s, const SetupArgs& a)
 }
 
 void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countA, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
-                           uint32_t nTiles, uint32_t cap, uint32_t* overflow, uint32_t* statusOut)
+                           uint32_t nTiles, uint32_t cap, uint32_t* overflow, uint32_t* statusOut, uint32_t* tileOrder)
 {
-	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, count, countA, countBig, offset, cursor, nTiles, cap, overflow, statusOut);
+	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, count, countA, countBig, offset, cursor, nTiles, cap, overflow, statusOut, tileOrder);
 }
 
 void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs)

@@ -309,27 +309,39 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 #define ALPHA_CHUNK 256 // entries staged per round by k_overshade
 #define ALPHA_STAGE 128 // and by k_raster_alpha (coverage + interpolation data: 27 KB, three workgroups per CU)
 
-struct AlphaCover {          // coverage + depth of one staged entry
+// Both staged records are 16-byte aligned so that the walk fetches them with 16-byte LDS reads (a ds_read2_b64 keeps the
+// LDS array busy twice as long per byte).
+struct __attribute__((aligned(16))) AlphaCover {          // coverage + depth of one staged entry
 	double e0, e1, e2;       // biased edge values at the tile's first pixel centre
 	double sx0, sx1, sx2;    // per pixel in x
 	double sy0, sy1, sy2;    // per pixel in y
 	double Az, Bz, Cz;
 	uint32_t prim;
 	uint32_t bbox;           // tile-local inclusive x0 | y0 << 8 | x1 << 16 | y1 << 24
+	uint32_t _pad[2];
 };
 
-struct AlphaAttr {           // what the alpha test of a fragment needs
+struct __attribute__((aligned(16))) AlphaAttr {           // what the alpha test of a fragment needs
 	double a[3], b[3], c[3];
 	float2 t0, t1, t2;
 	uint32_t off0, w0, h0;
 	int levels;
 };
 
+// Largest value over the 64 lanes, the same in every lane.  Data-parallel-primitive moves inside the vector ALU - a
+// shifted running maximum inside each row of 16 lanes, then the two row broadcasts - instead of six round trips
+// through the LDS crossbar (__shfl_xor): the pixel-owner kernels take this maximum once per batch of entries.
+// Lanes a move does not reach take 0, the identity of an unsigned maximum.
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-#pragma unroll
-	for (int k = 32; k >= 1; k >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, k, 64));
-	return v;
+	int x = (int)v;
+	x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false)); // row_shr:1
+	x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false)); // row_shr:2
+	x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false)); // row_shr:4
+	x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false)); // row_shr:8: lane 15 of a row holds the row's
+	x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1 and 3
+	x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2 and 3: lane 63 holds all
+	return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 
 // Straight-line footprint of the alpha fetch for a texture whose sizes are powers of two: both levels are always
@@ -668,6 +680,7 @@ __global__ __launch_bounds__(256 * ALPHA_PARTS) void k_raster_alpha(RasterArgs a
 // functions set up once per entry.
 // ---------------------------------------------------------------------------
 #define OS_SORT_CAP 4096u // bin entries sorted entirely in LDS (32 KB)
+#define OS_RADIX_MIN 512u  // bins longer than this take the radix sort (a flat ~9 us), shorter ones the bitonic network (45 steps at most)
 
 // Compare-exchange steps of the normalised bitonic network (every comparator puts the smaller word at the lower
 // index, so positions >= n behave as +infinity padding that never moves).  One step pairs i with i ^ mask.
@@ -690,6 +703,114 @@ __device__ __forceinline__ void os_lds_sort(unsigned long long* s, uint32_t m, u
 		os_lds_step(s, m, k - 1u, tid);
 		for (uint32_t j = k >> 2; j >= 1u; j >>= 1) os_lds_step(s, m, j, tid);
 	}
+}
+
+// Least-significant-digit radix sort of s[0, n) (n <= OS_SORT_CAP) by the primitive in the high word, 8 bits a pass, as
+// many passes as the largest primitive of the bin has bytes.  The (primitive | record) words stay where they are; the
+// passes permute 16-bit positions (permA <-> permB), and the words are moved once at the end.  A pass: every wavefront
+// ranks its 256 consecutive positions, 64 at a time (the lanes with equal digits find each other through eight
+// ballots; their rank is a popcount, the running count per (wavefront, digit) lives in hist), the 16 x 256 counts are
+// scanned digit-major, and the positions are scattered.  14 barriers for three passes against the 45-78 steps of
+// the bitonic network on 512-4096 entries.  scratch: OS_RADIX_SCRATCH bytes the caller does not need meanwhile.
+#define OS_RADIX_SCRATCH (2u * OS_SORT_CAP * 2u + 16u * 256u * 2u + 128u)
+__device__ __noinline__ void os_radix_sort(unsigned long long* s, uint32_t n, unsigned char* scratch, uint32_t tid)
+{
+	uint16_t* permA = (uint16_t*)scratch;
+	uint16_t* permB = permA + OS_SORT_CAP;
+	uint16_t* hist = permB + OS_SORT_CAP;          // [wavefront][digit]
+	uint32_t* wtot = (uint32_t*)(hist + 16 * 256); // per-wavefront totals of the scan, [16] = largest primitive
+	const uint32_t lane = tid & 63u, w = tid >> 6;
+	const unsigned long long ltMask = (1ull << lane) - 1ull;
+	// how many digits the keys have
+	if (tid == 0) wtot[16] = 0u;
+	__syncthreads();
+	{
+		uint32_t mx = 0;
+		for (uint32_t i = tid; i < n; i += 1024u) mx = max(mx, (uint32_t)(s[i] >> 32));
+		mx = wave_max_u32(mx);
+		if (lane == 0) atomicMax(&wtot[16], mx);
+	}
+	__syncthreads();
+	const uint32_t top = wtot[16];
+	const uint32_t passes = top < (1u << 8) ? 1u : top < (1u << 16) ? 2u : top < (1u << 24) ? 3u : 4u;
+	uint16_t* src = permA;
+	uint16_t* dst = permB;
+	const uint32_t nW = (n + 255u) >> 8; // wavefronts that hold positions; the others only keep the barriers
+	for (uint32_t pass = 0; pass < passes; pass++) {
+		const uint32_t shift = 8u * pass;
+		uint32_t idx[4], dig[4], loc[4];
+		bool val[4];
+		if (w < nW) {
+			for (uint32_t k = lane; k < 256u; k += 64u) hist[w * 256u + k] = 0;
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const uint32_t i = w * 256u + (uint32_t)r * 64u + lane;
+				val[r] = i < n;
+				idx[r] = 0u; dig[r] = 0u; loc[r] = 0u;
+				if (w * 256u + (uint32_t)r * 64u >= n) continue; // wave-uniform: nothing left for this wavefront
+				idx[r] = val[r] ? (pass ? (uint32_t)src[i] : i) : 0u;
+				dig[r] = val[r] ? (((uint32_t)(s[idx[r]] >> 32)) >> shift) & 255u : 0u;
+				unsigned long long peers = __ballot(val[r]);
+#pragma unroll
+				for (int b = 0; b < 8; b++) {
+					const unsigned long long bal = __ballot((dig[r] >> b) & 1u);
+					peers &= ((dig[r] >> b) & 1u) ? bal : ~bal;
+				}
+				const uint32_t rank = (uint32_t)__popcll(peers & ltMask);
+				uint32_t prev = 0;
+				if (val[r]) prev = hist[w * 256u + dig[r]];
+				__builtin_amdgcn_wave_barrier(); // every peer has read the count before their first lane raises it
+				if (val[r] && rank == 0) hist[w * 256u + dig[r]] = (uint16_t)(prev + (uint32_t)__popcll(peers));
+				__builtin_amdgcn_wave_barrier();
+				loc[r] = prev + rank;
+			}
+		} else {
+#pragma unroll
+			for (int r = 0; r < 4; r++) { val[r] = false; idx[r] = dig[r] = loc[r] = 0u; }
+		}
+		__syncthreads();
+		// exclusive scan of the counts in (digit, wavefront) order: thread t owns digit t / 4, wavefronts 4 (t % 4) .. + 3
+		{
+			const uint32_t d = tid >> 2, w0 = (tid & 3u) * 4u;
+			uint32_t c[4], sum = 0;
+#pragma unroll
+			for (int k = 0; k < 4; k++) { c[k] = (w0 + k < nW) ? (uint32_t)hist[(w0 + k) * 256u + d] : 0u; sum += c[k]; }
+			uint32_t inc = sum;
+#pragma unroll
+			for (int dd = 1; dd < 64; dd <<= 1) {
+				const uint32_t o = __shfl_up(inc, dd, 64);
+				if ((int)lane >= dd) inc += o;
+			}
+			if (lane == 63) wtot[w] = inc;
+			__syncthreads();
+			uint32_t base = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < 16u; k++) base += (k < w) ? wtot[k] : 0u;
+			uint32_t run = base + inc - sum;
+#pragma unroll
+			for (int k = 0; k < 4; k++) { if (w0 + k < nW) hist[(w0 + k) * 256u + d] = (uint16_t)run; run += c[k]; }
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+			if (val[r]) dst[hist[w * 256u + dig[r]] + loc[r]] = (uint16_t)idx[r];
+		__syncthreads();
+		uint16_t* t = src; src = dst; dst = t;
+	}
+	// move the words into their places
+	unsigned long long v[4];
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const uint32_t i = tid + (uint32_t)r * 1024u;
+		v[r] = (i < n) ? s[src[i]] : 0ull;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const uint32_t i = tid + (uint32_t)r * 1024u;
+		if (i < n) s[i] = v[r];
+	}
+	__syncthreads();
 }
 
 __device__ __forceinline__ void os_global_step(uint32_t* keys, uint32_t* vals, uint32_t n, uint32_t m, uint32_t mask, uint32_t tid)
@@ -731,11 +852,43 @@ __device__ __noinline__ void os_sort_long(unsigned long long* s, uint32_t* keys,
 	}
 }
 
-__global__ __launch_bounds__(1024) void k_overshade(OvershadeArgs a)
+// coverage + depth of one staged entry of k_overshade: edge values at the tile's first pixel centre, then the
+// per-pixel steps in x and in y (three each)
+// (16-byte aligned, so that the walk fetches it with 16-byte LDS reads: a ds_read2_b64 takes the LDS array twice as long
+// per byte, and with 16 wavefronts walking the array is what the deep tiles wait for)
+struct __attribute__((aligned(16))) OsCover {
+	double e[9];
+	double Az, Bz, Cz;
+	uint32_t bbox;           // tile-local inclusive x0 | y0 << 8 | x1 << 16 | y1 << 24
+	uint32_t _pad[3];
+};
+
+#ifdef VKR_WG_TIMES
+// measurement build only: per tile of the last k_overshade launch: start, sorted, done (100 MHz clock), bin entries
+__device__ unsigned long long g_osTimes[8 * 32768];
+extern "C" __attribute__((visibility("default"))) int vkr_debug_overshade_times(void* dst, size_t bytes)
 {
-	__shared__ AlphaCover sCov[ALPHA_CHUNK];
+	return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_osTimes), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+// 8 wavefronts per SIMD = two of these 16-wavefront workgroups per CU (LDS: 2 x 58 KB): one register over 64 would
+// leave every CU with a single workgroup, i.e. half the tiles in flight.
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_overshade(OvershadeArgs a)
+{
+#ifdef VKR_WG_TIMES
+	const unsigned long long osT0 = wall_clock64();
+#endif
+	__shared__ OsCover sCov[ALPHA_CHUNK];
 	__shared__ unsigned long long sSort[OS_SORT_CAP];
-	const uint32_t tile = blockIdx.x;
+#ifdef VKR_WG_TIMES
+	__shared__ uint32_t sStat[4]; // entries walked (summed over the wavefronts), the most by one wavefront, box hits culled by depth
+	if (threadIdx.x < 4) sStat[threadIdx.x] = 0;
+	uint32_t myHits = 0, myCulled = 0;
+#endif
+	// deepest bins first (the order comes from the tile scan): the kernel's time is the time of its longest tiles,
+	// which in raster order start somewhere in the middle of the launch
+	const uint32_t tile = a.tileOrder ? a.tileOrder[blockIdx.x] : blockIdx.x;
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
 	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = vkr_view_gy(a.view, ty * VKR_TILE);
 	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = oy + (int)min((uint32_t)VKR_TILE, a.view.rows - ty * VKR_TILE) - 1;
@@ -755,7 +908,13 @@ __global__ __launch_bounds__(1024) void k_overshade(OvershadeArgs a)
 	// submission order: the bin sorted by primitive (two fan triangles of one clipped primitive never cover the same
 	// pixel, so their mutual order is immaterial; the record index makes the order total all the same)
 	const bool inLds = n <= OS_SORT_CAP;
-	if (inLds) {
+	static_assert(sizeof(OsCover) * ALPHA_CHUNK >= OS_RADIX_SCRATCH, "the staging array doubles as the radix sort's scratch");
+	if (inLds && n > OS_RADIX_MIN) {
+		for (uint32_t i = tid; i < n; i += 1024u)
+			sSort[i] = ((unsigned long long)a.binKeys[beg + i] << 32) | a.binList[beg + i];
+		__syncthreads();
+		os_radix_sort(sSort, n, (unsigned char*)sCov, tid); // the staging array is idle until the walk
+	} else if (inLds) {
 		uint32_t m = 1u;
 		while (m < n) m <<= 1;
 		for (uint32_t i = tid; i < m; i += 1024u)
@@ -765,49 +924,83 @@ __global__ __launch_bounds__(1024) void k_overshade(OvershadeArgs a)
 	} else {
 		os_sort_long(sSort, a.binKeys + beg, a.binList + beg, n, tid);
 	}
+#ifdef VKR_WG_TIMES
+	__syncthreads();
+	const unsigned long long osT1 = wall_clock64();
+#endif
+#ifdef VKR_WG_TIMES
+	unsigned long long osStage = 0;
+#endif
 	for (uint32_t base = 0; base < n; base += ALPHA_CHUNK) {
 		__syncthreads();
+#ifdef VKR_WG_TIMES
+		const unsigned long long osS0 = wall_clock64();
+#endif
 		if (tid < ALPHA_CHUNK && base + tid < n) {
+			// (requesting the next chunk's record while this one is walked costs 16 registers the kernel does not have: spills, +8 %)
 			const SubTri s = a.recs[inLds ? (uint32_t)sSort[base + tid] : a.binList[beg + base + tid]];
-			AlphaCover& c = sCov[tid];
+			OsCover& c = sCov[tid];
 			int bx0, by0, bx1, by1;
 			tri_bbox(s, bx0, by0, bx1, by1);
 			bx0 = max(bx0, ox); by0 = max(by0, oy); bx1 = min(bx1, ex); by1 = min(by1, ey);
 			if (bx0 <= bx1 && by0 <= by1) {
 				EdgeSetup E;
 				edge_setup(s, ox, oy, E);
-				c.e0 = E.e0; c.e1 = E.e1; c.e2 = E.e2;
-				c.sx0 = E.sx0; c.sx1 = E.sx1; c.sx2 = E.sx2;
-				c.sy0 = E.sy0; c.sy1 = E.sy1; c.sy2 = E.sy2;
+				c.e[0] = E.e0; c.e[1] = E.e1; c.e[2] = E.e2;
+				c.e[3] = E.sx0; c.e[4] = E.sx1; c.e[5] = E.sx2;
+				c.e[6] = E.sy0; c.e[7] = E.sy1; c.e[8] = E.sy2;
 				c.Az = s.Az; c.Bz = s.Bz; c.Cz = s.Cz;
-				c.prim = s.prim;
 				c.bbox = (uint32_t)(bx0 - ox) | ((uint32_t)(by0 - oy) << 8) | ((uint32_t)(bx1 - ox) << 16) | ((uint32_t)(by1 - oy) << 24);
 			} else {
 				c.bbox = 0x0000ffffu; // x0 = y0 = 255 > x1 = y1 = 0: misses every block
 			}
 		}
 		__syncthreads();
+#ifdef VKR_WG_TIMES
+		osStage += wall_clock64() - osS0;
+#endif
 		const uint32_t m = min((uint32_t)ALPHA_CHUNK, n - base);
 		for (uint32_t j0 = 0; j0 < m; j0 += 64u) {
-			// 64 entries at a time: every lane tests one entry's bounding box against the wavefront's block; the
-			// entries that touch the block are then walked in order (the bits of the ballot, lowest first)
+			// 64 entries at a time: every lane tests one entry against the wavefront's block - its bounding box, and
+			// the nearest depth its plane can take over the block's pixel centres against the farthest depth the block
+			// holds (depths only come nearer while the batch is walked, so the bound taken here stays valid): an entry
+			// that lies behind everything drawn so far passes LESS_OR_EQUAL nowhere and changes nothing.  The entries
+			// left are then walked in order (the bits of the ballot, lowest first).
+			const float wfar = u2f(wave_max_u32(inRect ? f2u(depth) : 0u));
 			bool hit = false;
 			if (j0 + lane < m) {
-				const uint32_t bb = sCov[j0 + lane].bbox;
+				const OsCover& c = sCov[j0 + lane];
+				const uint32_t bb = c.bbox;
 				const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
 				hit = !(x1 < bxl || x0 > bxl + 7 || y1 < byl || y0 > byl + 7);
+				if (hit) {
+					// plane at the block's centre minus its largest change over 3.5 pixels either way, in double, rounded
+					// down: never above the depth of a fragment of the block (the plane's double value rounded to nearest)
+					const double Az = c.Az, Bz = c.Bz;
+					const float znear = __double2float_rd(fma(Az, (double)(ox + bxl) + 4.0, fma(Bz, (double)(oy + byl) + 4.0, c.Cz)) - 3.5 * (fabs(Az) + fabs(Bz)));
+#ifdef VKR_WG_TIMES
+					if (znear > wfar) myCulled++;
+#endif
+					hit = !(znear > wfar);
+				}
 			}
 			unsigned long long mask = __ballot(hit);
+#ifdef VKR_WG_TIMES
+			myHits += (uint32_t)__popcll(mask);
+#endif
 			while (mask) {
 				const uint32_t j = j0 + (uint32_t)(__ffsll((long long)mask) - 1);
 				mask &= mask - 1;
-				const AlphaCover& c = sCov[j];
-				const uint32_t bb = c.bbox;
-				const int x0 = (int)(bb & 255u), y0 = (int)((bb >> 8) & 255u), x1 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
-				const double e0 = fma(c.sy0, dly, fma(c.sx0, dlx, c.e0));
-				const double e1 = fma(c.sy1, dly, fma(c.sx1, dlx, c.e1));
-				const double e2 = fma(c.sy2, dly, fma(c.sx2, dlx, c.e2));
-				if (!(inRect && lx >= x0 && lx <= x1 && ly >= y0 && ly <= y1 && edges_inside(e0, e1, e2))) continue;
+				const OsCover& c = sCov[j];
+				// exact (integers below 2^53); a pixel centre inside all three edges lies inside the entry's bounding box, so
+				// there is no box test per lane.  (Entries with short edges evaluated in 32-bit integers instead - 24-bit
+				// multiplies, a sign test on the OR - is exact too, but the second code path costs registers the kernel does
+				// not have under its cap of 64: spills, +7 %.)
+				const double e0 = fma(c.e[6], dly, fma(c.e[3], dlx, c.e[0]));
+				const double e1 = fma(c.e[7], dly, fma(c.e[4], dlx, c.e[1]));
+				const double e2 = fma(c.e[8], dly, fma(c.e[5], dlx, c.e[2]));
+				const bool in = edges_inside(e0, e1, e2);
+				if (!(inRect && in)) continue;
 				const float z = vkr_depth_at(c.Az, c.Bz, c.Cz, px, py);
 				if (!(z >= 0.0f && z <= 1.0f)) continue;
 				if (!(z <= depth)) continue;
@@ -822,6 +1015,15 @@ __global__ __launch_bounds__(1024) void k_overshade(OvershadeArgs a)
 		a.countOut[p] = (uint8_t)cnt;
 		if (a.depthOut) a.depthOut[p] = depth;
 	}
+#ifdef VKR_WG_TIMES
+	if (lane == 0) { atomicAdd(&sStat[0], myHits); atomicMax(&sStat[1], myHits); }
+	atomicAdd(&sStat[2], myCulled);
+	__syncthreads();
+	if (tid == 0 && tile < 32768u) {
+		g_osTimes[8 * tile] = osT0; g_osTimes[8 * tile + 1] = osT1; g_osTimes[8 * tile + 2] = wall_clock64(); g_osTimes[8 * tile + 3] = n;
+		g_osTimes[8 * tile + 4] = sStat[0]; g_osTimes[8 * tile + 5] = sStat[1]; g_osTimes[8 * tile + 6] = sStat[2]; g_osTimes[8 * tile + 7] = osStage;
+	}
+#endif
 }
 
 void vkr_launch_raster(hipStream_t s, int mode, const RasterArgs& a)

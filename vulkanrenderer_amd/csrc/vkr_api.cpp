@@ -129,7 +129,7 @@ struct vkr_context {
 	float* dThresh = nullptr; // 255
 	float hDecode[256], hThresh[255];
 	// geometry scratch
-	DevBuf clip, planes, recs, recTiles, recLocal, clipQueue, bigQueue, zeroSets, tileOffset, cursor, tileFlags, binList, binKeys;
+	DevBuf clip, planes, recs, recTiles, recLocal, clipQueue, bigQueue, zeroSets, tileOffset, cursor, tileFlags, binList, binKeys, tileOrder;
 	// counters + per-tile counts of a pass, twice: a pass uses one set while its k_setup zeroes the other for the next pass
 	// layout of a set: 16 counters ([0] recCount, [1] overflow, [2] alpha tile count, [3] clip queue length,
 	// [4] big-record queue length, [5] deep alpha tile count), then tileCount, tileCountA, tileCountBig (zeroCapTiles each)
@@ -171,12 +171,12 @@ struct vkr_context {
 };
 
 // every device buffer a context owns
-#define VKR_CTX_NBUFS 23
+#define VKR_CTX_NBUFS 24
 static void ctx_bufs(vkr_context* c, DevBuf* out[VKR_CTX_NBUFS])
 {
 	DevBuf* all[VKR_CTX_NBUFS] = { &c->clip, &c->planes, &c->recs, &c->recTiles, &c->recLocal, &c->clipQueue, &c->bigQueue, &c->zeroSets,
 		&c->tileOffset, &c->cursor, &c->tileFlags, &c->binList, &c->binKeys, &c->vis, &c->depth, &c->triId, &c->gN, &c->gA, &c->colour,
-		&c->colour2, &c->stencil, &c->mip, &c->shadow };
+		&c->colour2, &c->stencil, &c->mip, &c->shadow, &c->tileOrder };
 	for (int i = 0; i < VKR_CTX_NBUFS; i++) out[i] = all[i];
 }
 
@@ -1110,7 +1110,7 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if ((rc = c->cursor.ensure((size_t)nTiles * 4))) return rc;
 	if ((rc = c->tileFlags.ensure((size_t)nTiles * 8))) return rc; // per-tile flags, then the list of deep tiles
 	if ((rc = c->binList.ensure((size_t)binCap * 4))) return rc;
-	if (g.keys && (rc = c->binKeys.ensure((size_t)binCap * 4))) return rc;
+	if (g.keys && ((rc = c->binKeys.ensure((size_t)binCap * 4)) || (rc = c->tileOrder.ensure((size_t)nTiles * 4)))) return rc;
 	// every buffer of the pass is in place; only now is the counter-set state touched, so an allocation failure
 	// above leaves the ping-pong pair as the last complete pass left it
 	if (nTiles > c->zeroCapTiles || !c->zeroSets.p) {
@@ -1141,8 +1141,9 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	}
 	{
 		StageTimer t(c, ST_BIN_SCAN);
+		// the overshading pass (the one that carries keys) also gets its tiles listed by descending bin length
 		vkr_launch_scan_tiles(c->stream, c->tileCount(), c->tileCountA(), c->tileCountBig(), c->tileOffset.as<uint32_t>(), c->cursor.as<uint32_t>(), nTiles,
-		                      binCap, counters + 1, &c->hStatus[statusSlot].recCount);
+		                      binCap, counters + 1, &c->hStatus[statusSlot].recCount, g.keys ? c->tileOrder.as<uint32_t>() : nullptr);
 	}
 	{
 		StageTimer t(c, ST_BIN_FILL);
@@ -1425,6 +1426,7 @@ static int submit_frame(vkr_context* c, const vkr_scene* s, const vkr_frame_para
 			o.view = view; o.recs = c->recs.as<SubTri>(); o.tileOffset = c->tileOffset.as<uint32_t>();
 			o.binList = c->binList.as<uint32_t>(); o.binKeys = c->binKeys.as<uint32_t>();
 			o.binCap = c->binCap; o.countOut = c->stencil.as<uint8_t>(); o.depthOut = c->depth.as<float>();
+			o.tileOrder = c->tileOrder.as<uint32_t>();
 			vkr_launch_overshade(c->stream, o);
 		}
 		{

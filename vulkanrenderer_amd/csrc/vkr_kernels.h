@@ -81,6 +81,7 @@ struct OvershadeArgs {
 	uint32_t binCap;
 	uint8_t* countOut;
 	float* depthOut;
+	const uint32_t* tileOrder; // tiles by descending bin length (k_scan_tiles), or NULL for raster order
 };
 
 struct ResolveArgs {
@@ -113,7 +114,7 @@ struct LightArgs {
 
 void vkr_launch_setup(hipStream_t s, const SetupArgs& a);
 void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countA, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
-                           uint32_t nTiles, uint32_t cap, uint32_t* overflow, uint32_t* statusOut);
+                           uint32_t nTiles, uint32_t cap, uint32_t* overflow, uint32_t* statusOut, uint32_t* tileOrder = nullptr);
 void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs);
 void vkr_launch_raster(hipStream_t s, int mode, const RasterArgs& a);
 void vkr_launch_overshade(hipStream_t s, const OvershadeArgs& a);
