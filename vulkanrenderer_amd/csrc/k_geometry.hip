@@ -362,6 +362,10 @@ __global__ __launch_bounds__(256) void k_count_big(SetupArgs a)
 // ---------------------------------------------------------------------------
 // exclusive scan of the per-tile counts (one workgroup), cursor reset
 // ---------------------------------------------------------------------------
+// bin-length class of a tile for the dispatch order: 0 = the longest bins
+__device__ __forceinline__ uint32_t tile_class(uint32_t n) { return n >= 1024u ? 0u : n >= 256u ? 1u : n >= 64u ? 2u : 3u; }
+
+template <bool ORDER> // ORDER: also list the tiles by descending bin length (tileOrder); the plain scan pays nothing for it
 __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ count, const uint32_t* __restrict__ countA,
                                                       const uint32_t* __restrict__ countBig,
                                                       uint32_t* __restrict__ offset, uint32_t* __restrict__ cursor, uint32_t nTiles,
@@ -371,19 +375,32 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 	// registers and meet in one barrier (a round per 1024 tiles is three barriers and a load round trip each)
 	__shared__ uint32_t wsum[8][16];
 	__shared__ uint32_t carry;
-	__shared__ uint32_t classCount[32]; // tiles per bin-length class (tileOrder only)
+	// tileOrder: tiles per (round, wavefront, class), turned into each wavefront's first position inside its class
+	#define SCAN_MAX_ROUNDS 8u // 65536 tiles; beyond that the order stays the raster order
+	__shared__ uint32_t wcls[SCAN_MAX_ROUNDS][16][4];
 	uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const bool ordered = ORDER && tileOrder && nTiles <= SCAN_MAX_ROUNDS * 8192u;
 	if (tid == 0) carry = 0;
-	if (tid < 32) classCount[tid] = 0;
 	__syncthreads();
+	uint32_t keep[8]; // the first round's lengths: most frames have no second round, and the order pass then reads nothing again
 	for (uint32_t base = 0; base < nTiles; base += 8192) {
 		uint32_t v[8], s[8];
+		uint32_t cc[4] = { 0, 0, 0, 0 };
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
 			const uint32_t i = base + j * 1024 + tid;
 			v[j] = (i < nTiles) ? count[i] + countA[i] + countBig[i] : 0u;
-			// class 0 = the longest bins: 31 - floor(log2(n | 1))
-			if (tileOrder && i < nTiles) atomicAdd(&classCount[__clz((int)(v[j] | 1u))], 1u);
+			if (ORDER && base == 0) keep[j] = v[j];
+		}
+		if (ORDER && ordered) {
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const bool in = base + j * 1024 + tid < nTiles;
+				const uint32_t c = tile_class(v[j]);
+#pragma unroll
+				for (uint32_t k = 0; k < 4; k++) cc[k] += (uint32_t)__popcll(__ballot(in && c == k));
+			}
+			if (lane < 4) wcls[base >> 13][wid][lane] = lane == 0 ? cc[0] : lane == 1 ? cc[1] : lane == 2 ? cc[2] : cc[3];
 		}
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
@@ -415,18 +432,52 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 		if (tid == 0) carry = running;
 		__syncthreads();
 	}
-	if (tileOrder) {
-		// A counting sort of the tiles by class, longest bins first: a kernel that gives one workgroup to every tile
-		// and whose time is set by its few deep tiles (k_overshade) starts those first.  The order inside a class is
-		// whatever the atomics make it; it schedules work and decides no result.
-		if (tid == 0) {
+	if (ORDER && tileOrder && !ordered)
+		for (uint32_t i = tid; i < nTiles; i += 1024u) tileOrder[i] = i;
+	if (ORDER && ordered) {
+		// A counting sort of the tiles by class, longest bins first: a kernel that gives one workgroup to every tile and
+		// whose time is set by its deepest tiles (k_overshade, the light's depth pass) starts those first.  Positions
+		// come from ballots and popcounts; inside a class the tiles keep their raster order.  The order schedules work
+		// and decides no result.
+		const uint32_t rounds = (nTiles + 8191u) >> 13;
+		__syncthreads();
+		if (wid == 0) {
+			// exclusive prefix over (class, round, wavefront), 64 at a time, by the first wavefront
+			const uint32_t Q = 4u * rounds * 16u;
 			uint32_t run = 0;
-			for (int k = 0; k < 32; k++) { const uint32_t c = classCount[k]; classCount[k] = run; run += c; }
+			for (uint32_t q0 = 0; q0 < Q; q0 += 64u) {
+				const uint32_t q = q0 + lane;
+				const uint32_t k = q / (rounds * 16u), r = (q / 16u) % rounds, w = q & 15u;
+				const uint32_t c = wcls[r][w][k];
+				uint32_t t = c;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) {
+					const uint32_t o = __shfl_up(t, d, 64);
+					if ((int)lane >= d) t += o;
+				}
+				wcls[r][w][k] = run + t - c;
+				run += (uint32_t)__shfl((int)t, 63, 64);
+			}
 		}
 		__syncthreads();
-		for (uint32_t i = tid; i < nTiles; i += 1024u) {
-			const uint32_t n = count[i] + countA[i] + countBig[i];
-			tileOrder[atomicAdd(&classCount[__clz((int)(n | 1u))], 1u)] = i;
+		const unsigned long long lt = (1ull << lane) - 1ull;
+		for (uint32_t base = 0; base < nTiles; base += 8192) {
+			uint32_t at[4];
+#pragma unroll
+			for (uint32_t k = 0; k < 4; k++) at[k] = wcls[base >> 13][wid][k];
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const uint32_t i = base + j * 1024 + tid;
+				const bool in = i < nTiles;
+				const uint32_t n = base == 0 ? keep[j] : (in ? count[i] + countA[i] + countBig[i] : 0u);
+				const uint32_t c = tile_class(n);
+#pragma unroll
+				for (uint32_t k = 0; k < 4; k++) {
+					const unsigned long long b = __ballot(in && c == k);
+					if (in && c == k) tileOrder[at[k] + (uint32_t)__popcll(b & lt)] = i;
+					at[k] += (uint32_t)__popcll(b);
+				}
+			}
 		}
 	}
 	if (tid == 0) {
@@ -520,7 +571,8 @@ void vkr_launch_setup(hipStream_t s, const SetupArgs& a)
 void vkr_launch_scan_tiles(hipStream_t s, const uint32_t* count, const uint32_t* countA, const uint32_t* countBig, uint32_t* offset, uint32_t* cursor,
                            uint32_t nTiles, uint32_t cap, uint32_t* overflow, uint32_t* statusOut, uint32_t* tileOrder)
 {
-	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, count, countA, countBig, offset, cursor, nTiles, cap, overflow, statusOut, tileOrder);
+	if (tileOrder) hipLaunchKernelGGL(k_scan_tiles<true>, dim3(1), dim3(1024), 0, s, count, countA, countBig, offset, cursor, nTiles, cap, overflow, statusOut, tileOrder);
+	else hipLaunchKernelGGL(k_scan_tiles<false>, dim3(1), dim3(1024), 0, s, count, countA, countBig, offset, cursor, nTiles, cap, overflow, statusOut, tileOrder);
 }
 
 void vkr_launch_bin_fill(hipStream_t s, const BinFillArgs& a, uint32_t maxRecs)

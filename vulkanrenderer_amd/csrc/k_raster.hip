@@ -152,7 +152,10 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a)
 	__shared__ unsigned long long tb64[MODE == RASTER_VIS ? VKR_TILE_PIX : 1];
 	__shared__ uint32_t tb32[MODE == RASTER_VIS ? 1 : VKR_TILE_PIX];
 	__shared__ int sAnyAlpha;
-	const uint32_t tile = blockIdx.x; // dispatch order: runs of tiles per XCD bought no time and cost L2 misses here (27 -> 31 MB)
+	// longest bins first (the order comes from the tile scan): the light's depth pass, whose bins are very uneven, ends
+	// a fifth sooner (101 -> 82 us for a 2048^2 map), the camera's pass by 1-2 %.  (Runs of neighbouring tiles per XCD
+	// bought no time here and cost L2 misses, 27 -> 31 MB.)
+	const uint32_t tile = a.tileOrder ? a.tileOrder[blockIdx.x] : blockIdx.x;
 	const uint32_t tx = tile % a.view.tilesX, ty = tile / a.view.tilesX;
 	const int ox = (int)(a.view.x0 + tx * VKR_TILE), oy = vkr_view_gy(a.view, ty * VKR_TILE);
 	const int ex = min(ox + VKR_TILE, (int)a.view.x1) - 1, ey = oy + (int)min((uint32_t)VKR_TILE, a.view.rows - ty * VKR_TILE) - 1; // inclusive

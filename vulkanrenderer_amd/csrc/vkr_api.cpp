@@ -140,6 +140,7 @@ struct vkr_context {
 	uint32_t* tileCountA() const { return zs(zset) + 16 + zeroCapTiles; }
 	uint32_t* tileCountBig() const { return zs(zset) + 16 + 2 * (size_t)zeroCapTiles; }
 	uint32_t recCap = 0, binCap = 0;
+	bool tileOrdered = false; // the last geometry pass left its tiles listed by descending bin length in tileOrder
 	double capScale = 1.0;
 	uint64_t binFloor = 0; // bin entries a pass has been seen to need (from an overflowed attempt)
 	// frame buffers
@@ -1110,7 +1111,8 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	if ((rc = c->cursor.ensure((size_t)nTiles * 4))) return rc;
 	if ((rc = c->tileFlags.ensure((size_t)nTiles * 8))) return rc; // per-tile flags, then the list of deep tiles
 	if ((rc = c->binList.ensure((size_t)binCap * 4))) return rc;
-	if (g.keys && ((rc = c->binKeys.ensure((size_t)binCap * 4)) || (rc = c->tileOrder.ensure((size_t)nTiles * 4)))) return rc;
+	if (g.keys && (rc = c->binKeys.ensure((size_t)binCap * 4))) return rc;
+	if ((rc = c->tileOrder.ensure((size_t)nTiles * 4))) return rc;
 	// every buffer of the pass is in place; only now is the counter-set state touched, so an allocation failure
 	// above leaves the ping-pong pair as the last complete pass left it
 	if (nTiles > c->zeroCapTiles || !c->zeroSets.p) {
@@ -1141,9 +1143,11 @@ static int run_geometry(vkr_context* c, const vkr_scene* s, const GeomPass& g, u
 	}
 	{
 		StageTimer t(c, ST_BIN_SCAN);
-		// the overshading pass (the one that carries keys) also gets its tiles listed by descending bin length
+		// for the passes whose bins are very uneven (the light's depth pass, the overshading pass) the scan also lists
+		// the tiles by descending bin length, and their per-tile kernels start the longest tiles first
+		c->tileOrdered = g.shadow || g.keys;
 		vkr_launch_scan_tiles(c->stream, c->tileCount(), c->tileCountA(), c->tileCountBig(), c->tileOffset.as<uint32_t>(), c->cursor.as<uint32_t>(), nTiles,
-		                      binCap, counters + 1, &c->hStatus[statusSlot].recCount, g.keys ? c->tileOrder.as<uint32_t>() : nullptr);
+		                      binCap, counters + 1, &c->hStatus[statusSlot].recCount, c->tileOrdered ? c->tileOrder.as<uint32_t>() : nullptr);
 	}
 	{
 		StageTimer t(c, ST_BIN_FILL);
@@ -1164,7 +1168,7 @@ static void fill_raster_args(vkr_context* c, const vkr_scene* s, const ViewDev& 
 	r.sc = s->dev; r.view = view; r.clip = c->clip.as<float4>(); r.planes = c->planes.as<TriPlanes>(); r.recs = c->recs.as<SubTri>();
 	r.tileOffset = c->tileOffset.as<uint32_t>(); r.tileCount = c->tileCount(); r.tileCountA = c->tileCountA(); r.binList = c->binList.as<uint32_t>(); r.binCap = c->binCap;
 	r.vis = nullptr; r.depthOut = nullptr; r.countOut = nullptr;
-	r.alphaTiles = c->tileFlags.as<uint32_t>(); r.alphaPass = 0;
+	r.alphaTiles = c->tileFlags.as<uint32_t>(); r.alphaPass = 0; r.tileOrder = c->tileOrdered ? c->tileOrder.as<uint32_t>() : nullptr;
 	r.deepTiles = c->tileFlags.as<uint32_t>() + (size_t)view.tilesX * view.tilesY; r.deepTileCount = c->counters() + 5; r.alphaTileCount = c->counters() + 2;
 }
 

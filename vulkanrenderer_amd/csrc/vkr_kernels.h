@@ -70,6 +70,7 @@ struct RasterArgs {
 	uint32_t* deepTiles;     // RASTER_VIS: the tiles with many alpha-tested entries (capacity: tiles)
 	uint32_t* deepTileCount; // its length (zeroed with the pass counters)
 	int alphaPass;           // RASTER_VIS: run the alpha-tested second pass
+	const uint32_t* tileOrder; // tiles by descending bin length (k_scan_tiles), or NULL for raster order
 };
 
 struct OvershadeArgs {
