@@ -48,16 +48,21 @@ __device__ __forceinline__ void edge_setup(const SubTri& s, int px, int py, Edge
 	const bool tl1 = (dy1 == 0 && dx1 > 0) || (dy1 < 0);
 	const bool tl2 = (dy2 == 0 && dx2 > 0) || (dy2 < 0);
 	// each product is an exact integer below 2^52; the fused subtraction is exact too
-	E.e0 = fma((double)dx0, (double)(PY - s.Y0), -((double)dy0 * (double)(PX - s.X0))) - (tl0 ? 0.0 : 1.0);
-	E.e1 = fma((double)dx1, (double)(PY - s.Y1), -((double)dy1 * (double)(PX - s.X1))) - (tl1 ? 0.0 : 1.0);
-	E.e2 = fma((double)dx2, (double)(PY - s.Y2), -((double)dy2 * (double)(PX - s.X2))) - (tl2 ? 0.0 : 1.0);
+	// (the bias is added, not subtracted: x + 0.0 is +0.0 where x - 0.0 would keep a -0.0, and edges_inside reads sign bits)
+	E.e0 = fma((double)dx0, (double)(PY - s.Y0), -((double)dy0 * (double)(PX - s.X0))) + (tl0 ? 0.0 : -1.0);
+	E.e1 = fma((double)dx1, (double)(PY - s.Y1), -((double)dy1 * (double)(PX - s.X1))) + (tl1 ? 0.0 : -1.0);
+	E.e2 = fma((double)dx2, (double)(PY - s.Y2), -((double)dy2 * (double)(PX - s.X2))) + (tl2 ? 0.0 : -1.0);
 	E.sx0 = -(double)dy0 * 256.0; E.sx1 = -(double)dy1 * 256.0; E.sx2 = -(double)dy2 * 256.0;
 	E.sy0 = (double)dx0 * 256.0; E.sy1 = (double)dx1 * 256.0; E.sy2 = (double)dx2 * 256.0;
 }
 
+// All three edge values >= 0.  They are integers held in doubles and never -0.0 (edge_setup adds +0.0 to the start
+// values, and neither a step added to such a value nor an exact cancellation gives -0.0 in round-to-nearest), so
+// the test is the sign bit of the three high words: one OR and one integer compare instead of the five double-precision
+// instructions (three of them NaN canonicalisations) of an fmin chain.
 __device__ __forceinline__ bool edges_inside(double e0, double e1, double e2)
 {
-	return fmin(e0, fmin(e1, e2)) >= 0.0;
+	return (__double2hiint(e0) | __double2hiint(e1) | __double2hiint(e2)) >= 0;
 }
 
 __device__ __forceinline__ void tri_bbox(const SubTri& s, int& px0, int& py0, int& px1, int& py1)
