@@ -279,7 +279,17 @@ def run(args):
                 raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible); use --backend gloo to rehearse with shared GPUs" % (rank, ndev))
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend="gloo")
+            # gloo announces its connections on stdout; the contract is one JSON line there, so its chatter goes to stderr
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend="gloo")
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             local_rank %= ndev
     if world != args.gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d; running %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
