@@ -404,12 +404,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 		}
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
-			uint32_t t = v[j]; // inclusive scan in the wave
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				uint32_t n = __shfl_up(t, d, 64);
-				if ((int)lane >= d) t += n;
-			}
+			const uint32_t t = vkr_wave_scan_incl_u32(v[j]);
 			s[j] = t;
 			if (lane == 63) wsum[j][wid] = t;
 		}
@@ -449,12 +444,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 				const uint32_t q = q0 + lane;
 				const uint32_t k = q / (rounds * 16u), r = (q / 16u) % rounds, w = q & 15u;
 				const uint32_t c = wcls[r][w][k];
-				uint32_t t = c;
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) {
-					const uint32_t o = __shfl_up(t, d, 64);
-					if ((int)lane >= d) t += o;
-				}
+				const uint32_t t = vkr_wave_scan_incl_u32(c);
 				wcls[r][w][k] = run + t - c;
 				run += (uint32_t)__shfl((int)t, 63, 64);
 			}

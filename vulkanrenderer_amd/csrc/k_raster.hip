@@ -783,12 +783,7 @@ __device__ __noinline__ void os_radix_sort(unsigned long long* s, uint32_t n, un
 			uint32_t c[4], sum = 0;
 #pragma unroll
 			for (int k = 0; k < 4; k++) { c[k] = (w0 + k < nW) ? (uint32_t)hist[(w0 + k) * 256u + d] : 0u; sum += c[k]; }
-			uint32_t inc = sum;
-#pragma unroll
-			for (int dd = 1; dd < 64; dd <<= 1) {
-				const uint32_t o = __shfl_up(inc, dd, 64);
-				if ((int)lane >= dd) inc += o;
-			}
+			const uint32_t inc = vkr_wave_scan_incl_u32(sum);
 			if (lane == 63) wtot[w] = inc;
 			__syncthreads();
 			uint32_t base = 0;

@@ -1687,7 +1687,7 @@ static int set_lanes_impl(vkr_context* c, uint32_t n)
 		l->profiling = c->profiling;
 		c->lanes.push_back(l);
 	}
-	c->nextLane = 0;
+	c->nextLane = 0; c->lastLane = 0;
 	return VKR_OK;
 }
 

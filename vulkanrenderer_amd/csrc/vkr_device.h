@@ -152,6 +152,23 @@ __host__ __device__ __forceinline__ bool vkr_view_local_rows(const ViewDev& v, i
 }
 
 // ---------------------------------------------------------------------------
+// wave-wide primitives on data-parallel-primitive moves (inside the vector ALU; a __shfl is a round trip through the
+// LDS crossbar).  Lanes a move does not reach take 0, the identity of both operations below.
+// ---------------------------------------------------------------------------
+// inclusive prefix sum over the 64 lanes: shifted sums inside each row of 16 lanes, then the two row broadcasts
+__device__ __forceinline__ uint32_t vkr_wave_scan_incl_u32(uint32_t v)
+{
+	int x = (int)v;
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); // row_shr:1
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); // row_shr:2
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); // row_shr:4
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false); // row_shr:8
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+	return (uint32_t)x;
+}
+
+// ---------------------------------------------------------------------------
 // bit helpers
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
