@@ -1,0 +1,366 @@
+"""Restatements written apart from the oracle's code, from the Vulkan rules themselves, that the oracle (here) and the
+HIP path (tests/test_parity_gpu.py) must meet: an exact integer rasteriser over Python integers for coverage, facing
+and depth; and a ray caster for texture coordinates, quad derivatives, level of detail and trilinear filtering of a
+tilted quad (main/shaders/gBufWrite.frag:16-27, debug.frag:19-38 with the sampler of utils/vkutil.cpp:179-196 and the
+mip chain of utils/vkimage.cpp:165-197, 289-294)."""
+import ctypes as C
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from conftest import IDENTITY, pose_matrix
+
+
+@pytest.fixture(scope="module")
+def L():
+    from oracle import oracle
+    return oracle.lib()
+
+
+# ---------------------------------------------------------------- coverage, facing, depth
+def exact_cover(clip, W, H, cull_back):
+    """One clip-space triangle (three rows x, y, z, w of float32 values, all w > 0, nothing to clip) rasterised with
+    Python integers and Fractions.
+
+    Window coordinates are snapped to 1/256 pixel.  A pixel centre is covered when it lies inside all three edges
+    after an infinitesimal move to the right and a still smaller one downwards: exactly the pixels the top-left rule
+    gives (a centre on a left edge moves inside, on a right edge outside; on a horizontal edge the move to the right
+    stays on the edge and the one downwards decides: inside below a top edge).  Facing follows the specification's
+    signed area a = -1/2 sum(x_i y_(i+1) - x_(i+1) y_i) in framebuffer coordinates: a > 0 is front with
+    frontFace = COUNTER_CLOCKWISE (main/main.cpp:2298-2305).  Depth is the plane through the three unsnapped window
+    positions with z/w at each, evaluated exactly at the centre.  Returns (mask, depth as Fractions or None)."""
+    c = [[float(np.float32(v)) for v in row] for row in clip]
+    sx = [(r[0] * (1.0 / r[3]) + 1.0) * (W * 0.5) for r in c]          # double arithmetic, as the rule states it
+    sy = [(r[1] * (1.0 / r[3]) + 1.0) * (H * 0.5) for r in c]
+    X = [int(np.floor(v * 256.0 + 0.5)) for v in sx]
+    Y = [int(np.floor(v * 256.0 + 0.5)) for v in sy]
+    S = sum(X[i] * Y[(i + 1) % 3] - X[(i + 1) % 3] * Y[i] for i in range(3))   # = -2a
+    mask = np.zeros((H, W), np.uint8)
+    if S == 0 or (cull_back and not S < 0):
+        return mask, None
+    sgn = 1 if S > 0 else -1
+    # exact depth plane over the unsnapped positions: z = z0 + gx (x - x0) + gy (y - y0)
+    fx = [Fraction(v) for v in sx]
+    fy = [Fraction(v) for v in sy]
+    fz = [Fraction(r[2]) / Fraction(r[3]) for r in c]
+    det = (fx[1] - fx[0]) * (fy[2] - fy[0]) - (fx[2] - fx[0]) * (fy[1] - fy[0])
+    plane = None
+    if det != 0:
+        gx = ((fz[1] - fz[0]) * (fy[2] - fy[0]) - (fz[2] - fz[0]) * (fy[1] - fy[0])) / det
+        gy = ((fx[1] - fx[0]) * (fz[2] - fz[0]) - (fx[2] - fx[0]) * (fz[1] - fz[0])) / det
+        plane = (gx, gy)
+    depth = {}
+    x_lo, x_hi = max(0, min(X) // 256 - 1), min(W - 1, max(X) // 256 + 1)
+    y_lo, y_hi = max(0, min(Y) // 256 - 1), min(H - 1, max(Y) // 256 + 1)
+    for py in range(y_lo, y_hi + 1):
+        for px in range(x_lo, x_hi + 1):
+            PX, PY = 256 * px + 128, 256 * py + 128
+            inside = True
+            for i in range(3):
+                j = (i + 1) % 3
+                ex, ey = X[j] - X[i], Y[j] - Y[i]
+                # cross(edge, P - V_i), its change per step to the right and per step downwards, oriented inwards
+                key = (sgn * (ex * (PY - Y[i]) - ey * (PX - X[i])), sgn * -ey, sgn * ex)
+                if not key > (0, 0, 0):
+                    inside = False
+                    break
+            if inside:
+                mask[py, px] = 1
+                if plane:
+                    depth[(py, px)] = fz[0] + plane[0] * (Fraction(2 * px + 1, 2) - fx[0]) + plane[1] * (Fraction(2 * py + 1, 2) - fy[0])
+    return mask, depth
+
+
+def random_triangle(rng, W, H):
+    """Window-space corners, half of them on the half-pixel lattice (pixel centres and pixel corners, where ties
+    between neighbouring triangles are decided), with random w and z/w in [0, 1]."""
+    rows = []
+    for _ in range(3):
+        if rng.random() < 0.5:
+            x, y = rng.integers(-4, 2 * W + 5) * 0.5, rng.integers(-4, 2 * H + 5) * 0.5
+        else:
+            x, y = rng.uniform(-3, W + 3), rng.uniform(-3, H + 3)
+        w = rng.uniform(0.5, 4.0) if rng.random() < 0.7 else 1.0
+        z = rng.uniform(0.0, 1.0)
+        rows.append([(x / W * 2 - 1) * w, (y / H * 2 - 1) * w, z * w, w])
+    return rows
+
+
+def test_coverage_facing_and_depth_against_exact_integer_rasteriser(L):
+    rng = np.random.default_rng(11)
+    fa = lambda v: (C.c_float * 4)(*[float(x) for x in v])
+    W, H = 24, 18
+    covered = ties = culled = 0
+    for n in range(600):
+        tri = random_triangle(rng, W, H)
+        if n % 7 == 0:                                  # an axis-aligned right triangle: horizontal and vertical edges
+            x0, y0 = rng.integers(0, W) + 0.5 * rng.integers(0, 2), rng.integers(0, H) + 0.5 * rng.integers(0, 2)
+            x1, y1 = x0 + rng.integers(1, 9), y0 + rng.integers(1, 9)
+            px = [(x0, y0), (x1, y0), (x0, y1)]
+            if rng.random() < 0.5:
+                px = [px[0], px[2], px[1]]
+            tri = [[x / W * 2 - 1, y / H * 2 - 1, 0.25 + 0.5 * k / 2, 1.0] for k, (x, y) in enumerate(px)]
+        for cull in (0, 1):
+            mask = np.zeros((H, W), np.uint8)
+            depth = np.full((H, W), -1.0, np.float32)
+            nsub = L.ora_coverage(fa(tri[0]), fa(tri[1]), fa(tri[2]), W, H, cull, mask.ctypes.data, depth.ctypes.data)
+            want, zs = exact_cover(tri, W, H, bool(cull))
+            assert np.array_equal(mask, want), "triangle %d cull %d: %d pixels differ" % (n, cull, int((mask != want).sum()))
+            if cull and want.sum() == 0 and exact_cover(tri, W, H, False)[0].sum():
+                culled += 1
+            covered += int(want.sum())
+            if zs:
+                # the oracle's depth is one double-precision plane evaluation rounded to float: 1e-6 covers that
+                # rounding and the conditioning of the plane for slivers (gradient times a 1/256 pixel is far larger)
+                for (py, px), z in zs.items():
+                    assert abs(float(z) - float(depth[py, px])) <= 1e-6 + 2e-7 * abs(float(z)), (n, px, py, float(z), float(depth[py, px]))
+        # ties: pixel centres exactly on an edge of the snapped triangle
+        c = [[float(np.float32(v)) for v in row] for row in tri]
+        X = [int(np.floor((r[0] * (1.0 / r[3]) + 1.0) * (W * 0.5) * 256.0 + 0.5)) for r in c]
+        Y = [int(np.floor((r[1] * (1.0 / r[3]) + 1.0) * (H * 0.5) * 256.0 + 0.5)) for r in c]
+        for i in range(3):
+            j = (i + 1) % 3
+            for py in range(H):
+                for px in range(W):
+                    PX, PY = 256 * px + 128, 256 * py + 128
+                    if (X[j] - X[i]) * (PY - Y[i]) - (Y[j] - Y[i]) * (PX - X[i]) == 0 and \
+                            min(X[i], X[j]) <= PX <= max(X[i], X[j]) and min(Y[i], Y[j]) <= PY <= max(Y[i], Y[j]):
+                        ties += 1
+    assert covered > 5000 and ties > 300 and culled > 100     # the cases the rules exist for all occurred
+
+
+def test_shared_edges_through_pixel_centres_are_drawn_once(L):
+    """Fans around pixel centres with spokes through other pixel centres: the exact rasteriser and the oracle agree
+    that every pixel of the frame belongs to exactly one triangle, whatever the winding."""
+    fa = lambda v: (C.c_float * 4)(*[float(x) for x in v])
+    W, H = 16, 12
+    rng = np.random.default_rng(2)
+    for centre in ((7.5, 5.5), (8.0, 6.0), (3.5, 9.5)):
+        ring = [(0, 0), (4.5, 0), (W, 0), (W, 5.5), (W, H), (9.5, H), (0, H), (0, 2.5)]
+        total = np.zeros((H, W), np.int32)
+        total_exact = np.zeros((H, W), np.int32)
+        for i in range(len(ring)):
+            a, b = ring[i], ring[(i + 1) % len(ring)]
+            tri = [[x / W * 2 - 1, y / H * 2 - 1, 0.5, 1.0] for x, y in (centre, a, b)]
+            if rng.random() < 0.5:
+                tri = [tri[0], tri[2], tri[1]]
+            mask = np.zeros((H, W), np.uint8)
+            L.ora_coverage(fa(tri[0]), fa(tri[1]), fa(tri[2]), W, H, 0, mask.ctypes.data, None)
+            total += mask
+            total_exact += exact_cover(tri, W, H, False)[0]
+        assert np.all(total_exact == 1) and np.all(total == 1)
+
+
+# ---------------------------------------------------------------- texture coordinates, level of detail, filtering
+def srgb_decode_np(c8):
+    c = c8.astype(np.float64) / 255.0
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+
+def srgb_encode8_np(lin):
+    e = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(np.maximum(lin, 0.0), 1 / 2.4) - 0.055)
+    return np.floor(np.clip(e, 0, 1) * 255.0 + 0.5)
+
+
+def mip_chain_np(rgba8, srgb):
+    """Level n = a LINEAR blit of level n - 1 (utils/vkimage.cpp:165-197): for sizes that halve, the destination
+    centre falls on the corner shared by a 2 x 2 block of source texels - their mean; a dimension already 1 texel
+    wide stays.  sRGB images are averaged in linear light (the colour channels) and stored as 8-bit codes again.
+    Returns the levels as float64 arrays of *decoded* values in [0, 1]."""
+    levels = []
+    cur = rgba8.astype(np.float64)
+    while True:
+        dec = cur / 255.0
+        if srgb:
+            dec = np.concatenate([srgb_decode_np(cur[..., :3]), cur[..., 3:] / 255.0], -1)
+        levels.append(dec)
+        h, w = cur.shape[:2]
+        if h == 1 and w == 1:
+            return levels
+        nh, nw = max(1, h // 2), max(1, w // 2)
+        assert (h == 1 or h == 2 * nh) and (w == 1 or w == 2 * nw)       # powers of two only in this restatement
+        d = dec.reshape(nh, h // nh, nw, w // nw, 4).mean(axis=(1, 3))
+        cur = np.floor(d * 255.0 + 0.5)
+        if srgb:
+            cur = np.concatenate([srgb_encode8_np(d[..., :3]), np.floor(d[..., 3:] * 255.0 + 0.5)], -1)
+
+
+def bilinear_repeat_np(level, u, v):
+    h, w = level.shape[:2]
+    x, y = u * w - 0.5, v * h - 0.5
+    x0, y0 = np.floor(x), np.floor(y)
+    fx, fy = (x - x0)[..., None], (y - y0)[..., None]
+    X0, X1 = x0.astype(np.int64) % w, (x0.astype(np.int64) + 1) % w
+    Y0, Y1 = y0.astype(np.int64) % h, (y0.astype(np.int64) + 1) % h
+    top = level[Y0, X0] * (1 - fx) + level[Y0, X1] * fx
+    bot = level[Y1, X0] * (1 - fx) + level[Y1, X1] * fx
+    return top * (1 - fy) + bot * fy
+
+
+def trilinear_np(levels, u, v, lam):
+    """mag = min = mip = LINEAR, REPEAT, no bias, lod clamped to the chain (utils/vkutil.cpp:179-196)."""
+    lam = np.clip(lam, 0.0, len(levels) - 1.0)
+    l0 = np.floor(lam).astype(int)
+    f = (lam - l0)[..., None]
+    out = np.zeros(u.shape + (4,))
+    for k in range(len(levels)):
+        m0, m1 = l0 == k, np.minimum(l0 + 1, len(levels) - 1) == k
+        if m0.any():
+            out[m0] += (bilinear_repeat_np(levels[k], u[m0], v[m0]) * (1 - f[m0]))
+        if m1.any():
+            out[m1] += (bilinear_repeat_np(levels[k], u[m1], v[m1]) * f[m1])
+    return out
+
+
+def ray_cast_quad(u, W, H, origin, du, dv, xs, ys):
+    """(s, t) of the point of the plane origin + s du + t dv seen at window positions (xs, ys): the two equations
+    clip.x = ndc.x clip.w, clip.y = ndc.y clip.w of the projected point, solved per position in float64."""
+    M = np.array(u.sceneUniforms.projCam, np.float64).reshape(4, 4).T
+    A = M @ np.append(origin, 1.0)
+    B = M @ np.append(du, 0.0)
+    Cc = M @ np.append(dv, 0.0)
+    nx, ny = xs / W * 2 - 1, ys / H * 2 - 1
+    a11, a12, b1 = B[0] - nx * B[3], Cc[0] - nx * Cc[3], nx * A[3] - A[0]
+    a21, a22, b2 = B[1] - ny * B[3], Cc[1] - ny * Cc[3], ny * A[3] - A[1]
+    det = a11 * a22 - a12 * a21
+    return (b1 * a22 - a12 * b2) / det, (a11 * b2 - b1 * a21) / det
+
+
+# A sample may differ from the prediction by one 8-bit step of a level's texels (a 2 x 2 mean that ends in .5 may be
+# rounded either way by a blit) plus half precision's 11 bits and float32 coordinates (a texel weight off by < 1e-4).
+TOL = 1.0 / 255.0 + 2e-3
+
+
+def check_sampling_against_ray_casting(make_scene_renderer, make_uniforms):
+    """A quad tilted about both axes, its texture coordinates skewed and repeated, textures of random texels: 64 x 64
+    sRGB base colour, 32 x 64 roughness, 64 x 64 metalness.  Predicted without rasterising anything: which pixels show
+    the quad, the level of detail written to `mip_level` (fine differences inside the 2 x 2 quad of ray-cast
+    coordinates, scaled by the base colour image's size, rho = the longer of the two difference vectors), and the
+    trilinear samples the G-buffer holds (base colour decoded before filtering; roughness and metalness from the red
+    channel of UNORM images with their own sizes and levels), and which fragments the alpha test discards.
+    make_scene_renderer(packed) -> render(params) -> buffers; make_uniforms(W, H, pose, debug)."""
+    from vulkanrenderer_amd import abi, scenes
+    rng = np.random.default_rng(21)
+    tex = lambda h, w, space: dict(rgba8=rng.integers(0, 256, (h, w, 4), dtype=np.uint8), space=space, channels=4)
+    textures = [tex(64, 64, 1), tex(64, 32, 0), tex(64, 64, 0),
+                dict(rgba8=np.tile(np.array([128, 128, 255, 255], np.uint8), (4, 4, 1)), space=0, channels=4)]
+    chains = [mip_chain_np(t["rgba8"], t["space"] == 1) for t in textures[:3]]
+    origin, du, dv = np.array([-3.0, -1.6, -2.5]), np.array([6.5, 0.4, -9.0]), np.array([0.3, 3.4, -1.2])
+    seen_levels = set()
+    kept = discarded = 0
+    for uv0, uv_du, uv_dv, W, H in (((0.13, 0.27), (5.0, 0.8), (-0.6, 2.5), 160, 90),
+                                    ((0.4, 0.1), (0.35, 0.05), (-0.02, 0.2), 128, 72),     # magnified
+                                    ((0.0, 0.5), (23.0, 3.0), (-4.0, 17.0), 96, 54)):      # far down the chain
+        mesh = scenes.grid_surface(origin, du, dv, 3, 2, uv0, uv_du, uv_dv, 0)
+        render = make_scene_renderer(abi.PackedScene(textures, [(0, 1, 2, 0xFFFFFFFF, 3, 0)], [mesh]))
+        for pose in (IDENTITY, pose_matrix(0.4, 0.2, 0.5, yaw=-0.25, pitch=0.1)):
+            u = make_uniforms(W, H, pose, 2)
+            view = render(abi.make_params(W, H, u, debug=2))
+            gb = render(abi.make_params(W, H, make_uniforms(W, H, pose, 1), deferred=True))
+            ys, xs = np.mgrid[0:H, 0:W]
+            s, t = ray_cast_quad(u, W, H, origin, du, dv, xs + 0.5, ys + 0.5)
+            uv = lambda s_, t_: (uv0[0] + s_ * uv_du[0] + t_ * uv_dv[0], uv0[1] + s_ * uv_du[1] + t_ * uv_dv[1])
+            U, V = uv(s, t)
+            # which pixels show the quad (it faces the camera in both poses; a margin of a hundredth of the quad
+            # keeps clear of the outline, where the 1/256-pixel snap decides)
+            inside = (s > 0.01) & (s < 0.99) & (t > 0.01) & (t < 0.99)
+            outside = (s < -0.01) | (s > 1.01) | (t < -0.01) | (t > 1.01)
+            hit = view["tri_id"] != 0xFFFFFFFF
+            assert inside.mean() > 0.2 and np.all(hit[inside]) and not np.any(hit[outside])
+            drawn = gb["tri_id"] != 0xFFFFFFFF
+            assert not np.any(drawn & ~hit)
+            # fine derivatives inside the 2 x 2 quad: f(x | 1) - f(x & ~1), f(y | 1) - f(y & ~1)
+            s_r, t_r = ray_cast_quad(u, W, H, origin, du, dv, (xs | 1) + 0.5, ys + 0.5)
+            s_l, t_l = ray_cast_quad(u, W, H, origin, du, dv, (xs & ~1) + 0.5, ys + 0.5)
+            s_d, t_d = ray_cast_quad(u, W, H, origin, du, dv, xs + 0.5, (ys | 1) + 0.5)
+            s_u, t_u = ray_cast_quad(u, W, H, origin, du, dv, xs + 0.5, (ys & ~1) + 0.5)
+            dUx, dVx = np.subtract(uv(s_r, t_r), uv(s_l, t_l))
+            dUy, dVy = np.subtract(uv(s_d, t_d), uv(s_u, t_u))
+            for ti, chain, got in ((0, chains[0], gb["gbuf_albedo"].view(np.float16).astype(np.float64)[..., :3]),
+                                   (1, chains[1], gb["gbuf_albedo"].view(np.float16).astype(np.float64)[..., 3]),
+                                   (2, chains[2], gb["gbuf_normal"].view(np.float16).astype(np.float64)[..., 3])):
+                th, tw = textures[ti]["rgba8"].shape[:2]
+                rho2 = np.maximum((dUx * tw) ** 2 + (dVx * th) ** 2, (dUy * tw) ** 2 + (dVy * th) ** 2)
+                lam = 0.5 * np.log2(rho2)
+                if ti == 0:
+                    lvl = np.clip(np.floor(lam), 0, len(chain) - 1).astype(np.uint8)
+                    sure = inside & (np.abs(lam - np.round(lam)) > 2e-3)
+                    assert np.array_equal(view["mip_level"][sure], lvl[sure]), \
+                        "level of detail differs at %d pixels" % int((view["mip_level"][sure] != lvl[sure]).sum())
+                    assert np.all(view["mip_level"][~hit] == 0xFF)
+                    seen_levels |= set(np.unique(lvl[sure]).tolist())
+                want = trilinear_np(chain, U[inside], V[inside], lam[inside])
+                if ti == 0:
+                    # the material names no alpha mask, so the base colour's alpha is what the G-buffer pass tests
+                    # (main/main.cpp:812-817, gBufWrite.frag:22-23): fragments below 0.5 are discarded there, while
+                    # the debug views draw every fragment (main/main.cpp:4164-4190)
+                    alpha = want[:, 3]
+                    assert np.all(drawn[inside][alpha > 0.5 + TOL]) and not np.any(drawn[inside][alpha < 0.5 - TOL])
+                    kept += int(drawn[inside].sum())
+                    discarded += int((~drawn[inside]).sum())
+                want = want[:, :3] if ti == 0 else want[:, 0]
+                err = np.abs(got[inside] - want)[drawn[inside]]
+                assert err.max() < TOL, "texture %d: sample differs by %.2e" % (ti, err.max())
+    assert {0, 1, 2, 3, 4} <= seen_levels, seen_levels
+    assert kept > 3000 and discarded > 3000
+
+
+def test_oracle_sampling_against_ray_casting():
+    from oracle import oracle
+    check_sampling_against_ray_casting(lambda packed: oracle.OracleScene(packed).render, oracle.make_uniforms)
+
+
+# ---------------------------------------------------------------- the light's depth pass
+def check_shadow_map_against_ray_casting(make_scene_renderer, make_uniforms):
+    """The depth map of the forward frame's first pass (shadowOffscreen.vert:9-11; pipeline main/main.cpp:3086-3137:
+    no culling, LESS_OR_EQUAL, depthBiasConstantFactor 7, depthBiasSlopeFactor 10, no clamp) of one tilted quad,
+    predicted by casting a ray through every texel centre with the light's matrix: depth of the plane there, plus
+    10 x the larger of its two window-space slopes, plus 7 x 2^(e - 23) with e the exponent of the primitive's largest
+    depth (the specification's r for a floating-point depth attachment; every depth of this quad lies in [0.5, 1), so
+    e = -1).  Texels off the quad keep the clear value 1."""
+    from vulkanrenderer_amd import abi, scenes
+    flat = lambda rgba, space: dict(rgba8=np.tile(np.array(rgba, np.uint8), (4, 4, 1)), space=space, channels=4)
+    textures = [flat((180, 180, 180, 255), 1), flat((128, 0, 0, 255), 0), flat((0, 0, 0, 255), 0), flat((128, 128, 255, 255), 0)]
+    S = 256
+    W, H = 64, 36
+    u = make_uniforms(W, H, IDENTITY, 1)
+    M = np.array(u.depthMVPUniform.depthMVP, np.float64).reshape(4, 4).T
+    checked = 0
+    for origin, du, dv in ((np.array([-6.0, 0.0, -40.0]), np.array([12.0, 1.5, 2.0]), np.array([1.0, -2.0, 22.0])),
+                           (np.array([-3.0, 2.0, -30.0]), np.array([5.0, -3.0, 0.5]), np.array([-1.0, 0.5, 9.0]))):
+        mesh = scenes.grid_surface(origin, du, dv, 1, 1, (0, 0), (1, 0), (0, 1), 0)
+        render = make_scene_renderer(abi.PackedScene(textures, [(0, 1, 2, 0xFFFFFFFF, 3, 0)], [mesh]))
+        sm = render(abi.make_params(W, H, u, shadow_size=S))["shadow_map"]
+        A, B, Cc = M @ np.append(origin, 1.0), M @ np.append(du, 0.0), M @ np.append(dv, 0.0)
+
+        def cast(xs, ys):
+            nx, ny = xs / S * 2 - 1, ys / S * 2 - 1
+            a11, a12, b1 = B[0] - nx * B[3], Cc[0] - nx * Cc[3], nx * A[3] - A[0]
+            a21, a22, b2 = B[1] - ny * B[3], Cc[1] - ny * Cc[3], ny * A[3] - A[1]
+            det = a11 * a22 - a12 * a21
+            s, t = (b1 * a22 - a12 * b2) / det, (a11 * b2 - b1 * a21) / det
+            clip = A[None, None, :] + s[..., None] * B + t[..., None] * Cc
+            return s, t, clip[..., 2] / clip[..., 3], clip[..., 3]
+        ys, xs = np.mgrid[0:S, 0:S]
+        s, t, z, w = cast(xs + 0.5, ys + 0.5)
+        zx = cast(xs + 1.5, ys + 0.5)[2] - z              # depth is affine in window space: differences are slopes
+        zy = cast(xs + 0.5, ys + 1.5)[2] - z
+        corners = [(M @ np.append(origin + a * du + b * dv, 1.0)) for a in (0, 1) for b in (0, 1)]
+        zc = [c[2] / c[3] for c in corners]
+        assert all(c[3] > 0 for c in corners) and 0.5 <= min(zc) and max(zc) < 1.0
+        want = np.minimum(z + 10.0 * np.maximum(np.abs(zx), np.abs(zy)) + 7.0 * 2.0 ** -24, 1.0)
+        inside = (s > 0.02) & (s < 0.98) & (t > 0.02) & (t < 0.98) & (w > 0)
+        outside = (s < -0.02) | (s > 1.02) | (t < -0.02) | (t > 1.02) | (w <= 0)
+        assert inside.sum() > 300
+        assert np.all(sm[outside] == 1.0)
+        err = np.abs(sm[inside].astype(np.float64) - want[inside])
+        assert err.max() <= 2.5e-7, "depth map differs from the biased plane by %.3g" % err.max()
+        assert np.all(sm[inside] > z[inside])                                       # the bias pushes away from the light
+        checked += int(inside.sum())
+    assert checked > 1000
+
+
+def test_oracle_shadow_map_against_ray_casting():
+    from oracle import oracle
+    check_shadow_map_against_ray_casting(lambda packed: oracle.OracleScene(packed).render, oracle.make_uniforms)

@@ -166,6 +166,40 @@ def test_flat_material_gbuffer_follows_the_conventions_gpu(gpu):
         sc.close()
 
 
+def test_sampling_against_ray_casting_gpu(gpu):
+    """The HIP path's coverage, `mip_level`, alpha test and G-buffer samples of a tilted, textured quad against the
+    ray-cast prediction of tests/test_independent_restatements.py (no oracle, no rasteriser in the prediction)."""
+    from test_independent_restatements import check_sampling_against_ray_casting
+    from vulkanrenderer_amd import renderer
+    ctx, _ = gpu
+    scenes_made = []
+
+    def make(packed):
+        sc = renderer.Scene(ctx, packed)
+        scenes_made.append(sc)
+        return sc.render
+    check_sampling_against_ray_casting(make, renderer.make_uniforms)
+    for sc in scenes_made:
+        sc.close()
+
+
+def test_shadow_map_against_ray_casting_gpu(gpu):
+    """The HIP path's light depth map of a tilted quad against the biased plane predicted by ray casting
+    (tests/test_independent_restatements.py): slope factor 10, constant factor 7, clear value off the quad."""
+    from test_independent_restatements import check_shadow_map_against_ray_casting
+    from vulkanrenderer_amd import renderer
+    ctx, _ = gpu
+    scenes_made = []
+
+    def make(packed):
+        sc = renderer.Scene(ctx, packed)
+        scenes_made.append(sc)
+        return sc.render
+    check_shadow_map_against_ray_casting(make, renderer.make_uniforms)
+    for sc in scenes_made:
+        sc.close()
+
+
 def test_deferred_with_shadow_pass_flag(gpu, micro_oracle):
     """VKR_FRAME_SHADOW_PASS: the deferred frame is unchanged and the light's depth map equals the forward path's
     (and the oracle's)."""
