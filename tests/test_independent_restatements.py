@@ -408,3 +408,77 @@ def check_clipped_floor_against_ray_casting(make_scene_renderer, make_uniforms):
 def test_oracle_clipped_floor_against_ray_casting():
     from oracle import oracle
     check_clipped_floor_against_ray_casting(lambda packed: oracle.OracleScene(packed).render, oracle.make_uniforms)
+
+
+# ---------------------------------------------------------------- overdraw and overshading counters
+def check_counters_against_ray_casting(make_scene_renderer, make_uniforms):
+    """Six quads that cross and overlap, one facing away, two of an alpha-masked material, submitted as six meshes:
+    the overdraw view counts every front-facing fragment (main/main.cpp:2758-2802: stencil INCREMENT_AND_CLAMP on
+    pass, depth test off in mode 5), the overshading view those that pass LESS_OR_EQUAL against what was drawn before
+    them - in the order of the model's mesh list, alpha-masked or not, and without the alpha test
+    (main/main.cpp:4111-4126).  Both predicted per pixel by casting a ray against each quad in that order."""
+    from vulkanrenderer_amd import abi, scenes
+    flat = lambda rgba, space: dict(rgba8=np.tile(np.array(rgba, np.uint8), (4, 4, 1)), space=space, channels=4)
+    rng = np.random.default_rng(4)
+    holes = dict(rgba8=rng.integers(0, 256, (16, 16, 4), dtype=np.uint8), space=0, channels=4)
+    textures = [flat((180, 180, 180, 255), 1), flat((128, 0, 0, 255), 0), flat((0, 0, 0, 255), 0), flat((128, 128, 255, 255), 0), holes]
+    materials = [(0, 1, 2, 0xFFFFFFFF, 3, 0), (0, 1, 2, 4, 3, 0)]
+    quads = [  # origin, du, dv, material; front face towards du x dv
+        ((-2.0, -1.5, -4.0), (4.0, 0.0, 0.0), (0.0, 3.0, 0.0), 1),        # near, alpha-masked, first in the list
+        ((-3.0, -2.0, -7.0), (6.0, 0.0, 0.0), (0.0, 4.0, 0.0), 0),        # far wall behind it
+        ((-2.5, -1.0, -3.0), (5.0, 0.0, -5.0), (0.0, 2.0, 0.0), 0),       # slanted, cuts through both
+        ((-1.0, -1.8, -5.0), (0.0, 3.6, 0.0), (2.0, 0.0, 0.0), 0),        # faces away: culled
+        ((-1.5, -0.5, -5.5), (3.0, 0.0, 1.0), (0.0, 1.5, 0.0), 1),        # alpha-masked, between the walls
+        ((-0.5, -2.0, -2.5), (1.0, 0.0, 0.0), (0.0, 4.0, -0.5), 0),       # a narrow strip in front of everything, last
+    ]
+    meshes = [scenes.grid_surface(np.array(o), np.array(a), np.array(b), 2, 2, (0, 0), (1, 0), (0, 1), m) for o, a, b, m in quads]
+    render = make_scene_renderer(abi.PackedScene(textures, materials, meshes))
+    orders_matter = 0
+    for W, H, pose in ((160, 90, IDENTITY), (131, 77, pose_matrix(0.4, 0.2, 0.3, yaw=-0.2, pitch=0.05))):
+        u5, u6 = make_uniforms(W, H, pose, 5), make_uniforms(W, H, pose, 6)
+        od = render(abi.make_params(W, H, u5, debug=5))["stencil"]
+        osd = render(abi.make_params(W, H, u6, debug=6))
+        M = np.array(u5.sceneUniforms.projCam, np.float64).reshape(4, 4).T
+        eye = np.array(list(u5.sceneUniforms.camPos)[:3], np.float64)
+        ys, xs = np.mgrid[0:H, 0:W]
+        layers, unsure = [], np.zeros((H, W), bool)
+        for o, a, b, _ in quads:
+            o, a, b = np.array(o), np.array(a), np.array(b)
+            if np.cross(a, b) @ (eye - o) <= 0:
+                continue                                                   # seen from behind: culled
+            s, t = ray_cast_quad(u5, W, H, o, a, b, xs + 0.5, ys + 0.5)
+            clip = (M @ np.append(o, 1.0))[None, None, :] + s[..., None] * (M @ np.append(a, 0.0)) + t[..., None] * (M @ np.append(b, 0.0))
+            z = clip[..., 2] / clip[..., 3]
+            inside = (s > 0) & (s < 1) & (t > 0) & (t < 1) & (clip[..., 3] > 0)
+            unsure |= (np.abs(s) < 0.02) | (np.abs(s - 1) < 0.02) | (np.abs(t) < 0.02) | (np.abs(t - 1) < 0.02)
+            layers.append((inside, z))
+        assert len(layers) == 5
+        want5 = sum(l[0].astype(np.int32) for l in layers)
+        cur = np.ones((H, W))
+        want6 = np.zeros((H, W), np.int32)
+        for inside, z in layers:
+            unsure |= inside & (np.abs(z - cur) < 1e-5)
+            passes = inside & (z <= cur)
+            want6 += passes
+            cur = np.where(passes, z, cur)
+        ok = ~unsure
+        assert ok.mean() > 0.6 and want5[ok].max() >= 4
+        assert np.array_equal(od[ok], want5[ok].astype(np.uint8))
+        assert np.array_equal(osd["stencil"][ok], want6[ok].astype(np.uint8))
+        assert np.abs(osd["depth_bits"].view(np.float32)[ok] - cur[ok]).max() < 5e-7
+        # the order is the mesh list's: with the alpha-masked meshes moved behind the opaque ones (the order of the
+        # colour passes, main/main.cpp:3873-3934) the count would differ at many pixels
+        cur2, alt = np.ones((H, W)), np.zeros((H, W), np.int32)
+        front = [q for q in quads if np.cross(np.array(q[1]), np.array(q[2])) @ (eye - np.array(q[0])) > 0]
+        for k in sorted(range(len(layers)), key=lambda k: front[k][3]):
+            inside, z = layers[k]
+            passes = inside & (z <= cur2)
+            alt += passes
+            cur2 = np.where(passes, z, cur2)
+        orders_matter += int((alt[ok] != want6[ok]).sum())
+    assert orders_matter > 200
+
+
+def test_oracle_counters_against_ray_casting():
+    from oracle import oracle
+    check_counters_against_ray_casting(lambda packed: oracle.OracleScene(packed).render, oracle.make_uniforms)

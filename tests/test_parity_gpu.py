@@ -217,6 +217,23 @@ def test_clipped_floor_against_ray_casting_gpu(gpu):
         sc.close()
 
 
+def test_counters_against_ray_casting_gpu(gpu):
+    """Overdraw and overshading counts of the HIP path over crossing quads (one culled, two alpha-masked) against the
+    per-pixel prediction by ray casting in mesh-list order (tests/test_independent_restatements.py)."""
+    from test_independent_restatements import check_counters_against_ray_casting
+    from vulkanrenderer_amd import renderer
+    ctx, _ = gpu
+    scenes_made = []
+
+    def make(packed):
+        sc = renderer.Scene(ctx, packed)
+        scenes_made.append(sc)
+        return sc.render
+    check_counters_against_ray_casting(make, renderer.make_uniforms)
+    for sc in scenes_made:
+        sc.close()
+
+
 def test_deferred_with_shadow_pass_flag(gpu, micro_oracle):
     """VKR_FRAME_SHADOW_PASS: the deferred frame is unchanged and the light's depth map equals the forward path's
     (and the oracle's)."""
