@@ -223,9 +223,29 @@ __device__ __forceinline__ bool tri_front(const SetupArgs& a, uint32_t t, TriFro
 // record slot of their own index; triangles that cross the
 // near plane or the guard band are queued for k_setup_clip, which keeps the
 // polygon clipper's local arrays (and their scratch memory) out of this kernel.
-__global__ __launch_bounds__(256) void k_setup(SetupArgs a)
+#ifdef VKR_WG_TIMES
+// measurement build: per-workgroup phase clocks (100 MHz) of the last k_setup launch
+__device__ unsigned long long g_setupTimes[8 * 4096];
+extern "C" __attribute__((visibility("default"))) int vkr_debug_setup_times(void* dst, size_t bytes)
 {
+	return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_setupTimes), bytes, 0, hipMemcpyDeviceToHost);
+}
+#define SETUP_CLOCK(k) do { if (threadIdx.x == 0) sClk[k] = wall_clock64(); } while (0)
+#else
+#define SETUP_CLOCK(k) do { } while (0)
+#endif
+
+// At most 80 scalar registers: a wavefront is given its count rounded up to 16 plus 16 more out of 800 per SIMD, so the 106 the
+// compiler would take leave room for six wavefronts per SIMD where the vector registers allow eight (the overflow is
+// kept in lanes of a vector register).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_setup(SetupArgs a)
+{
+#ifdef VKR_WG_TIMES
+	__shared__ unsigned long long sClk[6]; // in LDS, so that the measurement build keeps the registers of the real one
+	SETUP_CLOCK(0);
+#endif
 	__shared__ uint32_t sTag[SETUP_TABLE], sCnt[SETUP_TABLE], sBase[SETUP_TABLE];
+	__shared__ uint4 sStage[4][192]; // per wavefront: 32 triangles' planes or records on their way out
 	// the next pass's counters (the other set of the pair; nothing in flight uses it) are zeroed here, so that no pass
 	// needs a fill launch of its own
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.zeroWords; i += gridDim.x * blockDim.x) a.zeroBase[i] = 0u;
@@ -252,6 +272,7 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 			}
 		}
 	}
+	SETUP_CLOCK(1);
 	const unsigned long long qmask = __ballot(queue);
 	if (qmask) {
 		const int leader = __ffsll((long long)qmask) - 1;
@@ -267,9 +288,58 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 	if (t < a.first + a.count) {
 		// bit 31 of the second word: alpha-tested (bin fill then needs nothing else from the record)
 		// the interpolation planes: once per drawn triangle instead of once per shaded pixel
-		if (emit) { a.planes[t] = rec_planes; a.recs[slot] = rec; a.recTiles[slot] = make_uint2(tiles.x, tiles.y | ((rec.flags & VKR_ST_ALPHA) ? 0x80000000u : 0u)); }
+		if (emit) a.recTiles[slot] = make_uint2(tiles.x, tiles.y | ((rec.flags & VKR_ST_ALPHA) ? 0x80000000u : 0u));
 		else a.recTiles[slot] = make_uint2(0xffffffffu, 0u);
 	}
+	// The planes (96 B) and the record (64 B) of a wavefront's 64 triangles are neighbours in memory.  Stored lane by
+	// lane, every store instruction would scatter 64 separate 16-byte pieces over 4-6 KB (ten instructions, 640
+	// requests at the L2 per wavefront); staged through LDS half a wavefront at a time they leave as whole kilobytes
+	// (the same ten instructions, one request per line).  Pieces of triangles that draw nothing are not written.
+	{
+		const unsigned long long emask = __ballot(emit);
+		if (emask) {
+			uint4* stage = sStage[threadIdx.x >> 6];
+			const uint32_t l32 = lane & 31u;
+			uint4* dstP = (uint4*)(a.planes + (t - lane));
+			uint4* dstR = (uint4*)(a.recs + (slot - lane));
+			static_assert(sizeof(TriPlanes) == 96 && sizeof(SubTri) == 64, "six and four 16-byte pieces");
+			const double pd[12] = { rec_planes.a[0], rec_planes.a[1], rec_planes.a[2], rec_planes.b[0], rec_planes.b[1], rec_planes.b[2],
+			                        rec_planes.c[0], rec_planes.c[1], rec_planes.c[2], rec_planes.Az, rec_planes.Bz, rec_planes.Cz };
+#pragma unroll
+			for (uint32_t half = 0; half < 2; half++) {
+				if (!((emask >> (32u * half)) & 0xffffffffull)) continue; // wave-uniform
+				if (emit && (lane >> 5) == half) {
+#pragma unroll
+					for (int j = 0; j < 6; j++)
+						stage[l32 * 6u + j] = make_uint4((uint32_t)__double2loint(pd[2 * j]), (uint32_t)__double2hiint(pd[2 * j]),
+						                                 (uint32_t)__double2loint(pd[2 * j + 1]), (uint32_t)__double2hiint(pd[2 * j + 1]));
+				}
+				__builtin_amdgcn_wave_barrier();
+#pragma unroll
+				for (uint32_t i = 0; i < 3; i++) {
+					const uint32_t c = i * 64u + lane, owner = 32u * half + c / 6u;
+					if ((emask >> owner) & 1ull) dstP[192u * half + c] = stage[c];
+				}
+				__builtin_amdgcn_wave_barrier();
+				if (emit && (lane >> 5) == half) {
+					stage[l32 * 4u + 0] = make_uint4((uint32_t)rec.X0, (uint32_t)rec.Y0, (uint32_t)rec.X1, (uint32_t)rec.Y1);
+					stage[l32 * 4u + 1] = make_uint4((uint32_t)rec.X2, (uint32_t)rec.Y2, rec.prim, rec.flags);
+					stage[l32 * 4u + 2] = make_uint4((uint32_t)__double2loint(rec.Az), (uint32_t)__double2hiint(rec.Az),
+					                                 (uint32_t)__double2loint(rec.Bz), (uint32_t)__double2hiint(rec.Bz));
+					stage[l32 * 4u + 3] = make_uint4((uint32_t)__double2loint(rec.Cz), (uint32_t)__double2hiint(rec.Cz),
+					                                 (uint32_t)__double2loint(rec.bias), (uint32_t)__double2hiint(rec.bias));
+				}
+				__builtin_amdgcn_wave_barrier();
+#pragma unroll
+				for (uint32_t i = 0; i < 2; i++) {
+					const uint32_t c = i * 64u + lane, owner = 32u * half + c / 4u;
+					if ((emask >> owner) & 1ull) dstR[128u * half + c] = stage[c];
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+	}
+	SETUP_CLOCK(2);
 	const uint32_t tx0 = tiles.x & 0xffffu, ty0 = tiles.x >> 16, tx1 = tiles.y & 0xffffu, ty1 = tiles.y >> 16;
 	const uint32_t nt = emit ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0u;
 	// Records touching at most 8 tiles: the workgroup first counts per tile in an LDS table (its 256 consecutive
@@ -297,11 +367,13 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 		}
 	}
 	__syncthreads();
+	SETUP_CLOCK(3);
 	for (uint32_t h = threadIdx.x; h < SETUP_TABLE; h += blockDim.x) {
 		const uint32_t key = sTag[h];
 		if (key != 0xffffffffu) sBase[h] = atomicAdd(&((key & 0x80000000u) ? a.tileCountA : a.tileCount)[key & 0x7fffffffu], sCnt[h]);
 	}
 	__syncthreads();
+	SETUP_CLOCK(4);
 	if (small) {
 		uint32_t tx = tx0, ty = ty0;
 #pragma unroll
@@ -329,6 +401,24 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 		base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
 		if (nt > 8) a.bigQueue[base + (uint32_t)__popcll(bmask & ((1ull << lane) - 1ull))] = slot;
 	}
+#ifdef VKR_WG_TIMES
+	{
+		const uint32_t ne = (uint32_t)__popcll(__ballot(emit));
+		__shared__ uint32_t sEmit;
+		if (threadIdx.x == 0) sEmit = 0;
+		__syncthreads();
+		if (lane == 0) atomicAdd(&sEmit, ne);
+		__syncthreads();
+		if (threadIdx.x == 0 && blockIdx.x < 4096u) {
+			sClk[5] = wall_clock64();
+			for (int k = 0; k < 6; k++) g_setupTimes[8 * blockIdx.x + k] = sClk[k];
+			g_setupTimes[8 * blockIdx.x + 6] = sEmit;
+			uint32_t used = 0;
+			for (uint32_t h = 0; h < SETUP_TABLE; h++) used += sTag[h] != 0xffffffffu;
+			g_setupTimes[8 * blockIdx.x + 7] = used;
+		}
+	}
+#endif
 }
 
 // The queued triangles: polygon clip, fan, one record per fan triangle.
