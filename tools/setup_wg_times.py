@@ -41,5 +41,10 @@ ls = np.sort(T[T[:, 0] > 2.0, 0])
 print("   starts after 2 us (%d): " % len(ls) + " ".join("%.1f" % v for v in ls[:: max(1, len(ls) // 24)]))
 ends = np.sort(T[:, 5])
 print("   ends: first %.1f, 100th %.1f, 300th %.1f, 1000th %.1f us" % (ends[0], ends[99], ends[299], ends[999]))
+for x in (0, 3):
+    idx = np.arange(nwg)[np.arange(nwg) % 8 == x]           # workgroup i runs on XCD i % 8
+    first, rest = idx[idx < 2048], idx[idx >= 2048]
+    print("   XCD %d: its first ends %s; its late workgroups start %s" % (x, " ".join("%.1f" % v for v in np.sort(T[first, 5])[:14]),
+                                                                      " ".join("%.1f" % v for v in np.sort(T[rest, 0]))))
 late = np.argsort(T[:, 5])[-8:]
 print("   the eight last to finish: " + ", ".join("wg %d start %.1f end %.1f emitted %d tiles %d" % (i, T[i, 0], T[i, 5], b[i, 6], b[i, 7]) for i in late))
